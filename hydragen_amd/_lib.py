@@ -1,0 +1,130 @@
+"""
+ctypes binding of libhydragen_hip.so (C ABI: include/hydragen_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every
+operator raises `HydragenLibraryError` -- it never routes through torch or the CPU oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+HYD_MAX_LEVELS = 8
+HYD_F16, HYD_BF16, HYD_F32 = 0, 1, 2
+HYD_LSE_BQH, HYD_LSE_BHQ = 0, 1
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libhydragen_hip.so"
+
+
+class HydragenLibraryError(RuntimeError):
+    pass
+
+
+class PrefixParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p),
+        ("cu_seqlens_k", C.c_void_p), ("cu_seqlens_q", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("k_group_stride", C.c_int64), ("k_tok_stride", C.c_int64), ("k_head_stride", C.c_int64),
+        ("v_group_stride", C.c_int64), ("v_tok_stride", C.c_int64), ("v_head_stride", C.c_int64),
+        ("dtype", C.c_int32), ("B", C.c_int32), ("nq", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
+        ("D", C.c_int32), ("sb", C.c_int32), ("kv_len", C.c_int32), ("max_q_len", C.c_int32),
+        ("causal", C.c_int32), ("lse_layout", C.c_int32), ("num_splits", C.c_int32),
+    ]
+
+
+class Partial(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("lse", C.c_void_p), ("count", C.c_int32), ("is_f32", C.c_int32)]
+
+
+class SuffixParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p),
+        ("seq_lens_i32", C.c_void_p), ("seq_lens_i64", C.c_void_p),
+        ("k_batch_stride", C.c_int64), ("k_tok_stride", C.c_int64), ("k_head_stride", C.c_int64),
+        ("v_batch_stride", C.c_int64), ("v_tok_stride", C.c_int64), ("v_head_stride", C.c_int64),
+        ("dtype", C.c_int32), ("B", C.c_int32), ("nq", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
+        ("D", C.c_int32), ("kv_len", C.c_int32), ("n_partials", C.c_int32),
+        ("partials", Partial * HYD_MAX_LEVELS),
+    ]
+
+
+class Level(C.Structure):
+    _fields_ = [
+        ("k", C.c_void_p), ("v", C.c_void_p), ("cu_seqlens_k", C.c_void_p),
+        ("k_group_stride", C.c_int64), ("k_tok_stride", C.c_int64), ("k_head_stride", C.c_int64),
+        ("v_group_stride", C.c_int64), ("v_tok_stride", C.c_int64), ("v_head_stride", C.c_int64),
+        ("sb", C.c_int32), ("kv_len", C.c_int32),
+    ]
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [
+        ("suffix", SuffixParams), ("levels", Level * HYD_MAX_LEVELS),
+        ("n_levels", C.c_int32), ("reserved", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+# every symbol include/hydragen_hip.h declares
+EXPORTS = {
+    "hyd_version": (C.c_int, []),
+    "hyd_last_error_string": (C.c_char_p, []),
+    "hyd_prefix_plan": (C.c_int, [C.POINTER(PrefixParams), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hyd_prefix_workspace_bytes": (C.c_size_t, [C.POINTER(PrefixParams)]),
+    "hyd_prefix_attn_fwd": (C.c_int, [C.POINTER(PrefixParams), C.c_void_p]),
+    "hyd_suffix_attn_fwd": (C.c_int, [C.POINTER(SuffixParams), C.c_void_p]),
+    "hyd_combine_lse": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hyd_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeParams)]),
+    "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
+    "hyd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("HYDRAGEN_HIP_LIB", str(_LIB_PATH)))
+
+
+def load():
+    """Load the library (once).  torch is imported first so that the HIP runtime already mapped by
+    PyTorch-ROCm (same SONAME libamdhip64.so.7) is the one our kernels launch on."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves it)
+
+    p = lib_path()
+    if not p.exists():
+        raise HydragenLibraryError(
+            f"{p} not found: build it with `python hydragen_amd/csrc/build.py` "
+            "(or __graft_entry__.build()); there is no non-HIP fallback"
+        )
+    try:
+        lib = C.CDLL(str(p))
+    except OSError as e:  # pragma: no cover
+        raise HydragenLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in EXPORTS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HydragenLibraryError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().hyd_last_error_string().decode()
+        if rc == -1:
+            raise ValueError(f"hydragen_hip: {msg}")
+        if rc == -2:
+            raise NotImplementedError(f"hydragen_hip: {msg}")
+        raise RuntimeError(f"hydragen_hip error {rc}: {msg}")

@@ -1,0 +1,224 @@
+"""
+The Hydragen attention operator with the reference's signatures
+(/root/reference/hydragen/attention.py): `hydragen_attention` (:177-354),
+`hydragen_attention_nopad` (:357-392), `combine_lse` (:154-174).
+
+Decode (the hot path) is ONE C call, `hyd_decode_attn_fused`: a prefix pass per shared level
+on the matrix cores, then the suffix pass whose epilogue performs the log-sum-exp merge --
+2 kernel launches for the usual single-prefix case, no LSE re-layout copies, no scratch
+allocation inside the library.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import HYD_F32, HYD_LSE_BQH, HYD_MAX_LEVELS, DecodeParams
+from .flash import (
+    _dtype_code, _lastdim_contig, _require_gpu, _stream, fill_suffix_params, prefix_attention,
+)
+
+
+def combine_lse(outs: list[Tensor], lses: list[Tensor], enable_triton: bool = True):
+    """
+    Merge attention results using log-sum-exp metadata (attention.py:154-174).
+
+    Args:
+        outs: Attention results, list of [batch, seq_len, qheads, hdim]
+        lses: Log-sum-exps of outs, corresponding list of [batch, seq_len, qheads]
+        enable_triton: accepted for signature compatibility; one HIP kernel handles any
+            number of partials, any head dim and fp16/bf16/fp32 (attention.py:21-43 semantics).
+    """
+    assert len(outs) == len(lses) and len(outs) > 0
+    _require_gpu(*outs, *lses)
+    lib = _lib.load()
+    ref = outs[0]
+    for o, l in zip(outs, lses):
+        assert o.shape == ref.shape, f"{o.shape} {ref.shape}"
+        assert l.shape == ref.shape[:-1], f"{l.shape} {ref.shape}"
+        assert o.dtype == ref.dtype
+    if ref.dtype == torch.float32:
+        dt = HYD_F32
+    else:
+        dt = _dtype_code(ref)
+    outs_c = [o.contiguous() for o in outs]
+    lses_c = [l.contiguous().float() for l in lses]
+    n = len(outs_c)
+    D = ref.shape[-1]
+    rows = ref.numel() // D if D else 0
+    res = torch.empty(ref.shape, dtype=ref.dtype, device=ref.device)
+    op = (C.c_void_p * n)(*[o.data_ptr() for o in outs_c])
+    lp = (C.c_void_p * n)(*[l.data_ptr() for l in lses_c])
+    _lib.check(lib.hyd_combine_lse(op, lp, n, rows, D, dt, res.data_ptr(), None, _stream()))
+    return res
+
+
+def _fill_level(lv, sk: Tensor, sv: Tensor, scu, smax, use_varlen: bool, b: int):
+    if not use_varlen:
+        assert sk.ndim == 4, f"{sk.shape}"
+        ns = sk.shape[0]
+        assert b % ns == 0, f"{b} {ns}"
+        lv.k, lv.v = sk.data_ptr(), sv.data_ptr()
+        lv.cu_seqlens_k = None
+        lv.k_group_stride, lv.k_tok_stride, lv.k_head_stride = sk.stride(0), sk.stride(1), sk.stride(2)
+        lv.v_group_stride, lv.v_tok_stride, lv.v_head_stride = sv.stride(0), sv.stride(1), sv.stride(2)
+        lv.sb, lv.kv_len = ns, sk.shape[1]
+    else:
+        assert sk.ndim == 3, f"{sk.shape}"
+        assert scu is not None and scu.dtype == torch.int32
+        ns = scu.shape[0] - 1
+        assert b % ns == 0, f"{b} {ns}"
+        lv.k, lv.v = sk.data_ptr(), sv.data_ptr()
+        lv.cu_seqlens_k = scu.data_ptr()
+        lv.k_group_stride = lv.v_group_stride = 0
+        lv.k_tok_stride, lv.k_head_stride = sk.stride(0), sk.stride(1)
+        lv.v_tok_stride, lv.v_head_stride = sv.stride(0), sv.stride(1)
+        lv.sb, lv.kv_len = ns, int(smax)
+
+
+def hydragen_attention(
+    q: Tensor,
+    k: Tensor,
+    v: Tensor,
+    shared_ks: list[Tensor],
+    shared_vs: list[Tensor],
+    shared_cu_seq_lens: list[Tensor | None],
+    shared_max_seq_lens: list[int | None],
+    use_varlens: list[bool],
+    seq_lens: Tensor | None = None,
+):
+    """
+    Computes Hydragen attention (attention decomposition + inter-sequence batching); same
+    contract as attention.py:177-354.
+
+    Args:
+        q: attention queries, shape [batch, qlen, qheads, head_dim]
+        k, v: unique-per-sequence keys/values, shape [batch, kvlen, kvheads, head_dim]
+        shared_ks / shared_vs: per shared level, [sbatch, slen, kvheads, head_dim] when
+            use_varlens[i] is False, else packed [total_slen, kvheads, head_dim].  sbatch must
+            divide batch; sequence i uses shared sequence i // (batch / sbatch).
+        shared_cu_seq_lens: per level int32 [sbatch+1] cumulative lengths (varlen levels) or None
+        shared_max_seq_lens: per level max length (varlen levels) or None
+        use_varlens: per level, whether the packed format is used
+        seq_lens: lengths of the unique KVs (right padded).  If None the unique part is
+            attended causally (bottom-right aligned), as the reference does via flash-attn.
+    """
+    assert q.ndim == 4, f"{q.shape}"
+    assert k.ndim == 4, f"{k.shape}"
+    assert v.ndim == 4, f"{v.shape}"
+    assert k.shape == v.shape
+    assert (
+        len(shared_ks) == len(shared_vs) == len(shared_cu_seq_lens) == len(shared_max_seq_lens) == len(use_varlens)
+    )
+    for sk, sv in zip(shared_ks, shared_vs):
+        assert sk.shape == sv.shape, f"{sk.shape} {sv.shape}"
+    _require_gpu(q, k, v, *shared_ks, *shared_vs, seq_lens)
+    n_levels = len(shared_ks)
+    if n_levels > HYD_MAX_LEVELS:
+        raise NotImplementedError(f"at most {HYD_MAX_LEVELS} shared levels")
+
+    b, nq, hq, d = q.shape
+    q = q.contiguous()
+    k, v = _lastdim_contig(k), _lastdim_contig(v)
+    shared_ks = [_lastdim_contig(x) for x in shared_ks]
+    shared_vs = [_lastdim_contig(x) for x in shared_vs]
+
+    # seq_lens None means "causal over the unique part" in the reference (attention.py:343-345);
+    # with a single query the bottom-right-aligned causal mask hides nothing, which is the decode case.
+    fused_ok = seq_lens is not None or nq == 1 or k.shape[1] == 0
+    if fused_ok:
+        return _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens,
+                             use_varlens, seq_lens)
+
+    # unique-suffix prefill: per level prefix pass, causal MFMA pass over the unique K/V, N-way merge
+    outs, lses = [], []
+    for sk, sv, scu, smax, use_varlen in zip(shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens,
+                                             use_varlens):
+        o, l = _level_pass(q, sk, sv, scu, smax, use_varlen)
+        outs.append(o)
+        lses.append(l)
+    kvh = k.shape[2]
+    assert k.shape[0] == b and hq % kvh == 0
+    uo, ul = prefix_attention(
+        q, k, v, sb=b, kv_len=k.shape[1], group_stride=(k.stride(0), v.stride(0)),
+        tok_stride=(k.stride(1), v.stride(1)), head_stride=(k.stride(2), v.stride(2)),
+        B=b, nq=nq, causal=True, lse_layout=HYD_LSE_BQH, lse_shape=(b, nq, hq),
+    )
+    outs.append(uo)
+    lses.append(ul)
+    return combine_lse(outs, lses)
+
+
+def _level_pass(q, sk, sv, scu, smax, use_varlen):
+    b, nq, hq, d = q.shape
+    if not use_varlen:
+        ns = sk.shape[0]
+        assert b % ns == 0, f"{b} {ns}"
+        return prefix_attention(
+            q, sk, sv, sb=ns, kv_len=sk.shape[1], group_stride=(sk.stride(0), sv.stride(0)),
+            tok_stride=(sk.stride(1), sv.stride(1)), head_stride=(sk.stride(2), sv.stride(2)),
+            B=b, nq=nq, causal=False, lse_layout=HYD_LSE_BQH, lse_shape=(b, nq, hq),
+        )
+    ns = scu.shape[0] - 1
+    assert b % ns == 0, f"{b} {ns}"
+    return prefix_attention(
+        q, sk, sv, sb=ns, kv_len=int(smax), group_stride=(0, 0),
+        tok_stride=(sk.stride(0), sv.stride(0)), head_stride=(sk.stride(1), sv.stride(1)),
+        B=b, nq=nq, causal=False, lse_layout=HYD_LSE_BQH, lse_shape=(b, nq, hq), cu_seqlens_k=scu,
+    )
+
+
+def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens, use_varlens, seq_lens):
+    lib = _lib.load()
+    b, nq, hq, d = q.shape
+    out = torch.empty_like(q)
+    p = DecodeParams()
+    keep = [fill_suffix_params(p.suffix, q, k, v, seq_lens, out)]
+    p.n_levels = len(shared_ks)
+    for i, (sk, sv, scu, smax, uv) in enumerate(
+        zip(shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens, use_varlens)
+    ):
+        if uv:
+            scu = scu.contiguous()
+            keep.append(scu)
+        _fill_level(p.levels[i], sk, sv, scu, smax, uv, b)
+    if p.n_levels == 0:
+        assert k.shape[1] > 0, "no shared levels and no unique keys"
+    ws_bytes = lib.hyd_decode_workspace_bytes(C.byref(p))
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        keep.append(ws)
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
+    _lib.check(lib.hyd_decode_attn_fused(C.byref(p), _stream()))
+    return out
+
+
+def hydragen_attention_nopad(
+    q: Tensor,
+    k: Tensor,
+    v: Tensor,
+    shared_ks: List[Tensor],
+    shared_vs: List[Tensor],
+    seq_len: Optional[Tensor] = None,
+):
+    """
+    Hydragen attention when no shared level needs padding (attention.py:357-392).
+
+    Args:
+        q: [batch, qlen, qheads, head_dim]
+        k, v: unique-per-sequence keys/values [batch, kvlen, kvheads, head_dim]
+        shared_ks / shared_vs: list of [sbatch, slen, kvheads, head_dim]; sbatch divides batch
+        seq_len: lengths of the unique KVs (right padded); None = no padding
+    """
+    n = len(shared_ks)
+    return hydragen_attention(
+        q, k, v,
+        shared_ks=shared_ks, shared_vs=shared_vs,
+        shared_cu_seq_lens=[None] * n, shared_max_seq_lens=[None] * n, use_varlens=[False] * n,
+        seq_lens=seq_len,
+    )

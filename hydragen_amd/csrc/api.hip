@@ -1,0 +1,460 @@
+// C ABI of libhydragen_hip.so (see include/hydragen_hip.h): argument validation, shapes-only launch
+// planning, workspace carving.  No allocation, no synchronisation, no device reads on the host.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "hyd_kernels.h"
+
+using namespace hyd;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr int kNumCU = 256;  // MI355X
+constexpr int kMaxSplits = 32;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct PrefixPlan {
+    int g, per, row_blocks, nsplit, split_len, grid, qpg;
+};
+
+int check_common(int dtype, int B, int nq, int Hq, int Hkv, int D) {
+    if (dtype != HYD_F16 && dtype != HYD_BF16) return fail(HYD_ERR_UNSUPPORTED, "dtype %d: only f16/bf16", dtype);
+    if (D != 64 && D != 128) return fail(HYD_ERR_UNSUPPORTED, "head_dim %d: only 64 and 128 are implemented", D);
+    if (B <= 0 || nq <= 0 || Hq <= 0 || Hkv <= 0) return fail(HYD_ERR_BAD_ARG, "non-positive size B=%d nq=%d Hq=%d Hkv=%d", B, nq, Hq, Hkv);
+    if (Hq % Hkv != 0) return fail(HYD_ERR_BAD_ARG, "qheads %d not divisible by kvheads %d", Hq, Hkv);
+    return HYD_OK;
+}
+
+int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    int rc = check_common(p->dtype, p->B, p->nq, p->Hq, p->Hkv, p->D);
+    if (rc) return rc;
+    if (p->sb <= 0) return fail(HYD_ERR_BAD_ARG, "sb %d", p->sb);
+    if (p->kv_len < 0) return fail(HYD_ERR_BAD_ARG, "kv_len %d", p->kv_len);
+    pl->g = p->Hq / p->Hkv;
+    int qtok_per_group;
+    if (p->cu_seqlens_q) {
+        if (p->nq != 1) return fail(HYD_ERR_BAD_ARG, "cu_seqlens_q requires nq == 1 (packed query tokens)");
+        if (p->max_q_len <= 0) return fail(HYD_ERR_BAD_ARG, "cu_seqlens_q requires max_q_len > 0");
+        qtok_per_group = p->max_q_len;
+        pl->per = 1;
+    } else {
+        if (p->B % p->sb != 0) return fail(HYD_ERR_BAD_ARG, "batch %d not divisible by shared batch %d", p->B, p->sb);
+        pl->per = p->B / p->sb;
+        qtok_per_group = pl->per * p->nq;
+    }
+    pl->qpg = qtok_per_group;
+    const int64_t mrows = (int64_t)qtok_per_group * pl->g;
+    pl->row_blocks = (int)((mrows + 127) / 128);
+    const int64_t units = (int64_t)p->sb * p->Hkv * pl->row_blocks;
+    int ns = p->num_splits;
+    if (ns <= 0) {
+        // shapes-only heuristic: fill ~1.5 workgroups per CU, keep >= 256 keys per split
+        ns = 1;
+        if (units < (3 * kNumCU) / 4) {
+            const int max_by_len = p->kv_len / 256 > 0 ? p->kv_len / 256 : 1;
+            int want = (int)((3 * kNumCU / 2 + units - 1) / units);
+            ns = want < max_by_len ? want : max_by_len;
+        }
+    }
+    if (p->cu_seqlens_q) ns = 1;  // merged LSE re-layout needs uniform query counts
+    if (ns > kMaxSplits) ns = kMaxSplits;
+    if (ns < 1) ns = 1;
+    int split_len = (int)align_up((size_t)((p->kv_len + ns - 1) / ns), 128);
+    if (split_len == 0) split_len = 128;
+    ns = p->kv_len > 0 ? (p->kv_len + split_len - 1) / split_len : 1;
+    pl->nsplit = ns;
+    pl->split_len = split_len;
+    const int64_t grid = units * ns;
+    if (grid <= 0 || grid > 0x7fffffff) return fail(HYD_ERR_UNSUPPORTED, "grid too large");
+    pl->grid = (int)grid;
+    return HYD_OK;
+}
+
+size_t prefix_ws_bytes(const hyd_prefix_params* p, const PrefixPlan& pl) {
+    if (pl.nsplit <= 1) return 0;
+    const size_t rows = (size_t)p->B * p->nq * p->Hq;
+    return (size_t)pl.nsplit * (align_up(rows * p->D * sizeof(float), 256) + align_up(rows * sizeof(float), 256));
+}
+
+void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixArgs* a) {
+    memset(a, 0, sizeof(*a));
+    a->q = p->q;
+    a->k = p->k;
+    a->v = p->v;
+    a->cu_k = p->cu_seqlens_k;
+    a->cu_q = p->cu_seqlens_q;
+    a->k_gs = p->k_group_stride;
+    a->k_ts = p->k_tok_stride;
+    a->k_hs = p->k_head_stride;
+    a->v_gs = p->v_group_stride;
+    a->v_ts = p->v_tok_stride;
+    a->v_hs = p->v_head_stride;
+    a->B = p->B;
+    a->nq = p->nq;
+    a->Hq = p->Hq;
+    a->Hkv = p->Hkv;
+    a->g = pl.g;
+    a->sb = p->sb;
+    a->per = pl.per;
+    a->kv_len = p->kv_len;
+    a->row_blocks = pl.row_blocks;
+    a->nsplit = pl.nsplit;
+    a->split_len = pl.split_len;
+    a->lse_q_stride = pl.qpg;
+    a->scale_log2e = (1.0f / sqrtf((float)p->D)) * kLog2e;
+}
+
+// Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
+// `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
+int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s) {
+    PrefixArgs a;
+    fill_prefix_args(p, pl, &a);
+    const size_t rows = (size_t)p->B * p->nq * p->Hq;
+    if (pl.nsplit == 1) {
+        a.out = p->out;
+        a.lse = p->lse;
+        a.out_f32 = 0;
+        a.lse_layout = p->lse_layout;
+        int rc = launch_prefix(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
+        return rc ? fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc) : HYD_OK;
+    }
+    const size_t need = prefix_ws_bytes(p, pl);
+    if (!p->workspace || p->workspace_bytes < need)
+        return fail(HYD_ERR_WORKSPACE, "prefix pass needs %zu workspace bytes, got %zu", need, p->workspace_bytes);
+    const size_t o_bytes = align_up(rows * p->D * sizeof(float), 256);
+    const size_t l_bytes = align_up(rows * sizeof(float), 256);
+    char* ws = static_cast<char*>(p->workspace);
+    float* wo = reinterpret_cast<float*>(ws);
+    float* wl = reinterpret_cast<float*>(ws + (size_t)pl.nsplit * o_bytes);
+    a.out = wo;
+    a.lse = wl;
+    a.out_f32 = 1;
+    a.lse_layout = HYD_LSE_BQH;
+    a.out_split_stride = (int64_t)(o_bytes / sizeof(float));
+    a.lse_split_stride = (int64_t)(l_bytes / sizeof(float));
+    int rc = launch_prefix(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
+    if (rc) return fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc);
+    if (!merge) return HYD_OK;
+    CombineArgs c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < pl.nsplit; ++i) {
+        c.outs[i] = wo + (size_t)i * a.out_split_stride;
+        c.lses[i] = wl + (size_t)i * a.lse_split_stride;
+    }
+    c.n = pl.nsplit;
+    c.rows = (int64_t)rows;
+    c.D = p->D;
+    c.dtype_in = HYD_F32;
+    c.dtype_out = p->dtype;
+    c.out = p->out;
+    c.out_lse = p->lse;
+    c.lse_layout = p->lse_layout;
+    c.Hq = p->Hq;
+    c.qpg = pl.qpg;
+    rc = launch_combine(c, s);
+    return rc ? fail(HYD_ERR_LAUNCH, "combine kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
+int check_ptr_align(const void* p, const char* name) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "%s is null", name);
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) return fail(HYD_ERR_BAD_ARG, "%s must be 16-byte aligned", name);
+    return HYD_OK;
+}
+int check_stride8(int64_t s, const char* name) {
+    if (s % 8 != 0) return fail(HYD_ERR_BAD_ARG, "%s (%lld) must be a multiple of 8 elements", name, (long long)s);
+    return HYD_OK;
+}
+
+int check_suffix(const hyd_suffix_params* p, bool need_kv) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    int rc = check_common(p->dtype, p->B, p->nq, p->Hq, p->Hkv, p->D);
+    if (rc) return rc;
+    if (p->kv_len < 0) return fail(HYD_ERR_BAD_ARG, "kv_len %d", p->kv_len);
+    if ((rc = check_ptr_align(p->q, "q"))) return rc;
+    if ((rc = check_ptr_align(p->out, "out"))) return rc;
+    if (need_kv && p->kv_len > 0) {
+        if ((rc = check_ptr_align(p->k, "k"))) return rc;
+        if ((rc = check_ptr_align(p->v, "v"))) return rc;
+        if ((rc = check_stride8(p->k_batch_stride, "k_batch_stride")) || (rc = check_stride8(p->k_tok_stride, "k_tok_stride")) ||
+            (rc = check_stride8(p->k_head_stride, "k_head_stride")) || (rc = check_stride8(p->v_batch_stride, "v_batch_stride")) ||
+            (rc = check_stride8(p->v_tok_stride, "v_tok_stride")) || (rc = check_stride8(p->v_head_stride, "v_head_stride")))
+            return rc;
+    }
+    return HYD_OK;
+}
+
+int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts, hipStream_t s) {
+    SuffixArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = p->q;
+    a.k = p->k;
+    a.v = p->v;
+    a.out = p->out;
+    a.lse = p->lse;
+    a.sl32 = p->seq_lens_i32;
+    a.sl64 = p->seq_lens_i64;
+    a.k_bs = p->k_batch_stride;
+    a.k_ts = p->k_tok_stride;
+    a.k_hs = p->k_head_stride;
+    a.v_bs = p->v_batch_stride;
+    a.v_ts = p->v_tok_stride;
+    a.v_hs = p->v_head_stride;
+    a.B = p->B;
+    a.nq = p->nq;
+    a.Hq = p->Hq;
+    a.Hkv = p->Hkv;
+    a.g = p->Hq / p->Hkv;
+    a.kv_len = p->kv_len;
+    a.rows = p->nq * a.g;
+    a.units = p->B * p->Hkv;
+    a.scale_log2e = (1.0f / sqrtf((float)p->D)) * kLog2e;
+    const size_t rows = (size_t)p->B * p->nq * p->Hq;
+    int n = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        if (!parts[i].out || !parts[i].lse || parts[i].count <= 0)
+            return fail(HYD_ERR_BAD_ARG, "partial %d: null pointer or non-positive count", i);
+        for (int j = 0; j < parts[i].count; ++j) {
+            if (n >= kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "more than %d partials", kMaxCombine);
+            const size_t esz = parts[i].is_f32 ? 4 : 2;
+            // stacked slices are padded to 256 bytes exactly as hyd_prefix_attn_fwd lays them out
+            const size_t ostride = parts[i].count > 1 ? align_up(rows * p->D * esz, 256) : rows * p->D * esz;
+            const size_t lstride = parts[i].count > 1 ? align_up(rows * 4, 256) : rows * 4;
+            a.partials[n].out = static_cast<const char*>(parts[i].out) + (size_t)j * ostride;
+            a.partials[n].lse = reinterpret_cast<const float*>(reinterpret_cast<const char*>(parts[i].lse) + (size_t)j * lstride);
+            a.partials[n].is_f32 = parts[i].is_f32;
+            ++n;
+        }
+    }
+    a.n_partials = n;
+    int rc = launch_suffix(a, p->dtype, p->D, s);
+    return rc ? fail(HYD_ERR_LAUNCH, "suffix kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
+void level_to_prefix(const hyd_decode_params* p, int i, hyd_prefix_params* pp) {
+    const hyd_suffix_params& s = p->suffix;
+    const hyd_level& lv = p->levels[i];
+    memset(pp, 0, sizeof(*pp));
+    pp->q = s.q;
+    pp->k = lv.k;
+    pp->v = lv.v;
+    pp->cu_seqlens_k = lv.cu_seqlens_k;
+    pp->k_group_stride = lv.k_group_stride;
+    pp->k_tok_stride = lv.k_tok_stride;
+    pp->k_head_stride = lv.k_head_stride;
+    pp->v_group_stride = lv.v_group_stride;
+    pp->v_tok_stride = lv.v_tok_stride;
+    pp->v_head_stride = lv.v_head_stride;
+    pp->dtype = s.dtype;
+    pp->B = s.B;
+    pp->nq = s.nq;
+    pp->Hq = s.Hq;
+    pp->Hkv = s.Hkv;
+    pp->D = s.D;
+    pp->sb = lv.sb;
+    pp->kv_len = lv.kv_len;
+    pp->causal = 0;
+    pp->lse_layout = HYD_LSE_BQH;
+    pp->num_splits = 0;
+}
+
+// per-level workspace: nsplit == 1 -> one dtype slice + lse; nsplit > 1 -> fp32 slices (prefix_ws_bytes)
+size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl) {
+    const size_t rows = (size_t)pp.B * pp.nq * pp.Hq;
+    if (pl.nsplit > 1) return prefix_ws_bytes(&pp, pl);
+    return align_up(rows * pp.D * 2, 256) + align_up(rows * 4, 256);
+}
+
+int check_prefix_ptrs(const hyd_prefix_params* p) {
+    int rc;
+    if ((rc = check_ptr_align(p->q, "q"))) return rc;
+    if ((rc = check_ptr_align(p->k, "shared k"))) return rc;
+    if ((rc = check_ptr_align(p->v, "shared v"))) return rc;
+    if ((rc = check_stride8(p->k_group_stride, "k_group_stride")) || (rc = check_stride8(p->k_tok_stride, "k_tok_stride")) ||
+        (rc = check_stride8(p->k_head_stride, "k_head_stride")) || (rc = check_stride8(p->v_group_stride, "v_group_stride")) ||
+        (rc = check_stride8(p->v_tok_stride, "v_tok_stride")) || (rc = check_stride8(p->v_head_stride, "v_head_stride")))
+        return rc;
+    return HYD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hyd_version(void) { return HYD_VERSION; }
+
+const char* hyd_last_error_string(void) { return g_err; }
+
+int hyd_prefix_plan(const hyd_prefix_params* p, int32_t* num_splits, int32_t* grid, int32_t* split_len) {
+    PrefixPlan pl;
+    int rc = plan_prefix(p, &pl);
+    if (rc) return rc;
+    if (num_splits) *num_splits = pl.nsplit;
+    if (grid) *grid = pl.grid;
+    if (split_len) *split_len = pl.split_len;
+    return HYD_OK;
+}
+
+size_t hyd_prefix_workspace_bytes(const hyd_prefix_params* p) {
+    PrefixPlan pl;
+    if (plan_prefix(p, &pl)) return 0;
+    return prefix_ws_bytes(p, pl);
+}
+
+int hyd_prefix_attn_fwd(const hyd_prefix_params* p, void* stream) {
+    PrefixPlan pl;
+    int rc = plan_prefix(p, &pl);
+    if (rc) return rc;
+    if ((rc = check_prefix_ptrs(p))) return rc;
+    if ((rc = check_ptr_align(p->out, "out"))) return rc;
+    if (p->kv_len == 0) return fail(HYD_ERR_BAD_ARG, "kv_len == 0: attention over no keys is undefined");
+    return run_prefix(p, pl, /*merge=*/true, static_cast<hipStream_t>(stream));
+}
+
+int hyd_suffix_attn_fwd(const hyd_suffix_params* p, void* stream) {
+    int rc = check_suffix(p, true);
+    if (rc) return rc;
+    if (p->n_partials < 0 || p->n_partials > HYD_MAX_LEVELS) return fail(HYD_ERR_BAD_ARG, "n_partials %d", p->n_partials);
+    if (p->kv_len == 0 && p->n_partials == 0) return fail(HYD_ERR_BAD_ARG, "kv_len == 0 and no partials");
+    return run_suffix(p, p->partials, p->n_partials, static_cast<hipStream_t>(stream));
+}
+
+int hyd_combine_lse(const void* const* outs, const float* const* lses, int32_t n, int64_t rows, int32_t D,
+                    int32_t dtype, void* out, float* out_lse, void* stream) {
+    if (!outs || !lses || !out) return fail(HYD_ERR_BAD_ARG, "null pointer");
+    if (n <= 0 || n > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "n = %d partials (1..%d supported)", n, kMaxCombine);
+    if (rows < 0 || D <= 0) return fail(HYD_ERR_BAD_ARG, "rows %lld D %d", (long long)rows, D);
+    if (dtype != HYD_F16 && dtype != HYD_BF16 && dtype != HYD_F32) return fail(HYD_ERR_UNSUPPORTED, "dtype %d", dtype);
+    CombineArgs c;
+    memset(&c, 0, sizeof(c));
+    bool aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    for (int i = 0; i < n; ++i) {
+        if (!outs[i] || !lses[i]) return fail(HYD_ERR_BAD_ARG, "partial %d is null", i);
+        c.outs[i] = outs[i];
+        c.lses[i] = lses[i];
+        aligned = aligned && (reinterpret_cast<uintptr_t>(outs[i]) & 15u) == 0;
+    }
+    c.n = n;
+    c.rows = rows;
+    c.D = D;
+    c.dtype_in = dtype;
+    c.dtype_out = dtype;
+    c.out = out;
+    c.out_lse = out_lse;
+    c.lse_layout = HYD_LSE_BQH;
+    c.scalar_only = aligned ? 0 : 1;  // unaligned views take the element-wise kernel
+    int rc = launch_combine(c, static_cast<hipStream_t>(stream));
+    return rc ? fail(HYD_ERR_LAUNCH, "combine kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
+size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {
+    if (!p || p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return 0;
+    size_t total = 0;
+    for (int i = 0; i < p->n_levels; ++i) {
+        hyd_prefix_params pp;
+        level_to_prefix(p, i, &pp);
+        PrefixPlan pl;
+        if (plan_prefix(&pp, &pl)) return 0;
+        total += level_ws_bytes(pp, pl);
+    }
+    return total;
+}
+
+size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32_t D, int32_t n_levels,
+                           const int32_t* level_sb, const int32_t* level_kv_len) {
+    if (n_levels < 0 || n_levels > HYD_MAX_LEVELS) return 0;
+    hyd_decode_params p;
+    memset(&p, 0, sizeof(p));
+    p.suffix.dtype = HYD_BF16;
+    p.suffix.B = B;
+    p.suffix.nq = nq;
+    p.suffix.Hq = Hq;
+    p.suffix.Hkv = Hkv;
+    p.suffix.D = D;
+    p.n_levels = n_levels;
+    for (int i = 0; i < n_levels; ++i) {
+        p.levels[i].sb = level_sb[i];
+        p.levels[i].kv_len = level_kv_len[i];
+    }
+    return hyd_decode_workspace_bytes(&p);
+}
+
+int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    if (p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return fail(HYD_ERR_BAD_ARG, "n_levels %d", p->n_levels);
+    const hyd_suffix_params& sp = p->suffix;
+    int rc = check_suffix(&sp, true);
+    if (rc) return rc;
+    if (p->n_levels == 0 && sp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "no shared levels and no unique keys");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t rows = (size_t)sp.B * sp.nq * sp.Hq;
+
+    // attention.py:273-274: single level, empty unique KV -> the prefix result is the answer
+    if (p->n_levels == 1 && sp.kv_len == 0) {
+        hyd_prefix_params pp;
+        level_to_prefix(p, 0, &pp);
+        PrefixPlan pl;
+        if ((rc = plan_prefix(&pp, &pl))) return rc;
+        if ((rc = check_prefix_ptrs(&pp))) return rc;
+        pp.out = sp.out;
+        pp.lse = nullptr;
+        pp.workspace = p->workspace;
+        pp.workspace_bytes = p->workspace_bytes;
+        return run_prefix(&pp, pl, true, s);
+    }
+
+    const size_t need = hyd_decode_workspace_bytes(p);
+    if (need > 0 && (!p->workspace || p->workspace_bytes < need))
+        return fail(HYD_ERR_WORKSPACE, "decode needs %zu workspace bytes, got %zu", need, p->workspace_bytes);
+
+    hyd_partial parts[HYD_MAX_LEVELS];
+    char* ws = static_cast<char*>(p->workspace);
+    for (int i = 0; i < p->n_levels; ++i) {
+        hyd_prefix_params pp;
+        level_to_prefix(p, i, &pp);
+        PrefixPlan pl;
+        if ((rc = plan_prefix(&pp, &pl))) return rc;
+        if ((rc = check_prefix_ptrs(&pp))) return rc;
+        if (pp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "level %d has kv_len == 0", i);
+        const size_t bytes = level_ws_bytes(pp, pl);
+        if (pl.nsplit == 1) {
+            pp.out = ws;
+            pp.lse = reinterpret_cast<float*>(ws + align_up(rows * sp.D * 2, 256));
+            parts[i].out = pp.out;
+            parts[i].lse = pp.lse;
+            parts[i].count = 1;
+            parts[i].is_f32 = 0;
+        } else {
+            pp.workspace = ws;
+            pp.workspace_bytes = bytes;
+            parts[i].out = ws;
+            parts[i].lse = reinterpret_cast<const float*>(ws + (size_t)pl.nsplit * align_up(rows * sp.D * 4, 256));
+            parts[i].count = pl.nsplit;
+            parts[i].is_f32 = 1;
+        }
+        if ((rc = run_prefix(&pp, pl, /*merge=*/false, s))) return rc;
+        ws += bytes;
+    }
+    if (sp.kv_len == 0) {
+        // several levels, no unique keys: merge the level partials only (suffix contributes lse = -inf)
+        hyd_suffix_params s0 = sp;
+        s0.seq_lens_i32 = nullptr;
+        s0.seq_lens_i64 = nullptr;
+        return run_suffix(&s0, parts, p->n_levels, s);
+    }
+    return run_suffix(&sp, parts, p->n_levels, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Kernel argument blocks + launcher prototypes shared by the C-ABI layer (api.hip) and the kernels.
+#pragma once
+#include "hyd_common.h"
+
+namespace hyd {
+
+constexpr int kMaxCombine = 64;  // partials one combine launch / one suffix epilogue can merge
+
+struct PrefixArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;   // dtype [..] or fp32 when out_f32; split sp writes at out + sp*out_split_stride
+    float* lse;  // may be null
+    const int32_t* cu_k;
+    const int32_t* cu_q;
+    int64_t k_gs, k_ts, k_hs, v_gs, v_ts, v_hs;
+    int64_t out_split_stride;  // elements
+    int64_t lse_split_stride;  // elements
+    int32_t B, nq, Hq, Hkv, g, sb, per;
+    int32_t kv_len;
+    int32_t lse_q_stride;  // BHQ layout: query tokens per group
+    int32_t row_blocks, nsplit, split_len;
+    int32_t lse_layout, out_f32;
+    float scale_log2e;
+};
+
+struct PartialDev {
+    const void* out;
+    const float* lse;
+    int32_t is_f32;
+    int32_t pad;
+};
+
+struct SuffixArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    float* lse;
+    const int32_t* sl32;
+    const int64_t* sl64;
+    int64_t k_bs, k_ts, k_hs, v_bs, v_ts, v_hs;
+    int32_t B, nq, Hq, Hkv, g, kv_len;
+    int32_t rows;  // nq * g
+    int32_t units; // B * Hkv
+    int32_t n_partials;
+    float scale_log2e;
+    PartialDev partials[kMaxCombine];
+};
+
+struct CombineArgs {
+    const void* outs[kMaxCombine];
+    const float* lses[kMaxCombine];
+    void* out;
+    float* out_lse;
+    int64_t rows;
+    int32_t n, D, dtype_in, dtype_out;  // dtype_in may be HYD_F32 with a 16-bit dtype_out
+    // optional BHQ re-layout of out_lse: row = tok*Hq + h -> ((tok / qpg)*Hq + h)*qpg + tok % qpg
+    int32_t lse_layout, Hq, qpg;
+    int32_t scalar_only;  // force the element-wise kernel (unaligned tensors)
+};
+
+// launchers (defined next to the kernels); return hipError_t as int
+int launch_prefix(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
+int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
+int launch_combine(const CombineArgs& a, hipStream_t s);
+
+}  // namespace hyd

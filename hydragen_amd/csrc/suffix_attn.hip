@@ -1,0 +1,275 @@
+// Suffix pass (K2 + K3 of SURVEY.md, with K4/K5 fused into the epilogue): every query row of
+// sequence b against the first seq_len[b] keys of b's own (unique) K/V.  ~1 flop/byte: this is an
+// HBM-bandwidth kernel, so it is built around wide coalesced loads and many bytes in flight, not MFMA.
+//
+// Replaces /root/reference/hydragen/flash.py:163-281 flash_attention_seqlen
+//   (= hydragen/xformers_stuff.py:189-428 _fwd_kernel_splitK + hydragen/flash.py:76-160 _splitK_reduce)
+// and, when partials are passed, hydragen/attention.py:352 combine_lse (:21-43 semantics, N partials).
+//
+// Mapping (wave64): a "unit" is one (sequence b, kv head).  D/8 lanes cover one key row with a 16-byte
+// load each, so one wave instruction fetches 64/(D/8) consecutive keys (4 at D=128).  WPU waves share a
+// unit (key iterations interleaved across them); 4/WPU units per 256-thread workgroup, consecutive
+// waves = consecutive kv heads of the same sequence, i.e. neighbouring 2*D-byte pieces of the same token
+// rows.  q.k partial dot products use v_dot2 and are reduced across the D/8 lanes with DPP adds; each
+// lane group runs its own online softmax over its keys; groups, then waves, are merged at the end.
+#include "hyd_kernels.h"
+
+namespace hyd {
+
+template <typename T>
+__device__ __forceinline__ void widen8(const u32x4& v, float (&f)[8]) {
+    using TR = Traits<T>;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = TR::lo(v[i]);
+        f[2 * i + 1] = TR::hi(v[i]);
+    }
+}
+
+// merge (m, l, acc) state pairs; all values in base-2 domain
+__device__ __forceinline__ void merge_state(float& m, float& l, float (&acc)[8], float m2, float l2,
+                                            const float (&acc2)[8]) {
+    const float mf = fmaxf(m, m2);
+    const float ms = (mf == -INFINITY) ? 0.f : mf;
+    const float a1 = fast_exp2(m - ms), a2 = fast_exp2(m2 - ms);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a1 + acc2[j] * a2;
+    m = mf;
+}
+
+template <typename T, int D, int R, int WPU>
+__global__ __launch_bounds__(256) void suffix_attn_kernel(const SuffixArgs a) {
+    using TR = Traits<T>;
+    constexpr int LPK = D / 8;    // lanes per key row
+    constexpr int KPI = 64 / LPK; // keys per wave instruction
+    constexpr int U = (R <= 2) ? 8 : 4;  // key iterations in flight
+    __shared__ float xbuf[WPU > 1 ? (WPU - 1) * R * (2 + D) : 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane % LPK, ks = lane / LPK;
+    const int wv = wave % WPU;
+    const int unit = blockIdx.x * (4 / WPU) + wave / WPU;
+    if (unit >= a.units) return;  // uniform per unit (all WPU waves of a unit leave together)
+    const int b = unit / a.Hkv, hk = unit % a.Hkv;
+    const int row0 = blockIdx.y * R;
+
+    int len = a.kv_len;
+    if (a.sl32) len = a.sl32[b];
+    else if (a.sl64) len = (int)a.sl64[b];
+    len = max(0, min(len, a.kv_len));
+
+    // ---- query rows (packed 16-bit pairs, 8 dims per lane) -------------------------------------
+    u32x4 qp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (row < a.rows) {
+            const int iq = row / a.g, gq = row % a.g;
+            const uint16_t* qr = static_cast<const uint16_t*>(a.q) +
+                                 (((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq) * D + sub * 8;
+            qp[r] = *reinterpret_cast<const u32x4*>(qr);
+        } else {
+            qp[r] = z;
+        }
+    }
+
+    const uint16_t* kb_ = static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs + sub * 8;
+    const uint16_t* vb_ = static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs + sub * 8;
+
+    float m[R], l[R], acc[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        m[r] = -INFINITY;
+        l[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+    }
+
+    const int niter = (len + KPI * WPU - 1) / (KPI * WPU);
+    const float sc = a.scale_log2e;
+    for (int it = 0; it < niter; it += U) {
+        u32x4 kreg[U], vreg[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = ((it + u) * WPU + wv) * KPI + ks;
+            valid[u] = key < len;
+            // never predicate the loads (a branch per load serialises them): clamp to the last valid key,
+            // its score is forced to -inf below so it contributes exactly 0
+            const int kc = min(key, len - 1);
+            kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb_ + (int64_t)kc * a.k_ts));
+            vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb_ + (int64_t)kc * a.v_ts));
+        }
+        float s[R][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d = TR::dot2(qp[r][i], kreg[u][i], d);
+                d = group_sum<LPK>(d);
+                s[r][u] = valid[u] ? d * sc : -INFINITY;
+            }
+        }
+        float vf[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) widen8<T>(vreg[u], vf[u]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float cmax = s[r][0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) cmax = fmaxf(cmax, s[r][u]);
+            const float mn = fmaxf(m[r], cmax);
+            const float ms = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = fast_exp2(m[r] - ms);
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r][j] *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = fast_exp2(s[r][u] - ms);
+                ps += p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(p, vf[u][j], acc[r][j]);
+            }
+            l[r] = l[r] * alpha + ps;
+            m[r] = mn;
+        }
+    }
+
+    // ---- merge the KPI lane groups of the wave (butterfly: every lane ends with the total) -----
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float m2 = __shfl_xor(m[r], off);
+            const float l2 = __shfl_xor(l[r], off);
+            float a2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a2[j] = __shfl_xor(acc[r][j], off);
+            merge_state(m[r], l[r], acc[r], m2, l2, a2);
+        }
+    }
+
+    // ---- merge the WPU waves of the unit through LDS -------------------------------------------
+    if (WPU > 1) {
+        float* xb = xbuf;  // [(WPU-1)][R][2 + D]
+        if (wv > 0 && ks == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float* p = xb + ((wv - 1) * R + r) * (2 + D);
+                if (sub == 0) {
+                    p[0] = m[r];
+                    p[1] = l[r];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[2 + sub * 8 + j] = acc[r][j];
+            }
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 1; w < WPU; ++w)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float* p = xb + ((w - 1) * R + r) * (2 + D);
+                float a2[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a2[j] = p[2 + sub * 8 + j];
+                merge_state(m[r], l[r], acc[r], p[0], p[1], a2);
+            }
+    }
+
+    // ---- epilogue: normalise, merge with the prefix partials (attention.py:21-43), store -------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= a.rows || ks != (r % KPI)) continue;
+        const int iq = row / a.g, gq = row % a.g;
+        const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;  // [B, nq, Hq]
+        const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
+        const float lse_s = l[r] > 0.f ? m[r] * kLn2 + __logf(l[r]) : -INFINITY;
+        if (a.lse && sub == 0) a.lse[ridx] = lse_s;
+        float num[8];
+        if (a.n_partials == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) num[j] = acc[r][j] * inv;
+        } else {
+            float M = lse_s;
+            for (int i = 0; i < a.n_partials; ++i) M = fmaxf(M, a.partials[i].lse[ridx]);
+            const float Ms = (M == -INFINITY) ? 0.f : M;
+            const float ws = __expf(lse_s - Ms);
+            float den = ws;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) num[j] = acc[r][j] * (inv * ws);
+            for (int i = 0; i < a.n_partials; ++i) {
+                const float w = __expf(a.partials[i].lse[ridx] - Ms);
+                den += w;
+                float pv[8];
+                if (a.partials[i].is_f32) {
+                    const float* po = static_cast<const float*>(a.partials[i].out) + ridx * D + sub * 8;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(po);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(po + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pv[j] = x0[j];
+                        pv[4 + j] = x1[j];
+                    }
+                } else {
+                    const uint16_t* po = static_cast<const uint16_t*>(a.partials[i].out) + ridx * D + sub * 8;
+                    widen8<T>(*reinterpret_cast<const u32x4*>(po), pv);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
+            }
+            const float dinv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) num[j] *= dinv;
+        }
+        u32x4 pk = {TR::pack2(num[0], num[1]), TR::pack2(num[2], num[3]), TR::pack2(num[4], num[5]),
+                    TR::pack2(num[6], num[7])};
+        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(a.out) + ridx * D + sub * 8) = pk;
+    }
+}
+
+template <typename T, int D, int R>
+static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
+    // Shapes-only choice: spread one unit over the 4 waves of a workgroup when there are too few
+    // units to fill 256 CUs with one wave each (C3-like shapes).
+    const int row_chunks = (a.rows + R - 1) / R;
+    const bool few_units = (int64_t)a.units * row_chunks < 2 * 256 * 4 && a.kv_len >= 64;
+    if (few_units) {
+        dim3 grid(a.units, row_chunks);
+        hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 4>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((a.units + 3) / 4, row_chunks);
+        hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T, int D>
+static int launch_suffix_t(const SuffixArgs& a, hipStream_t s) {
+    if (a.rows <= 1) return launch_suffix_r<T, D, 1>(a, s);
+    if (a.rows <= 2) return launch_suffix_r<T, D, 2>(a, s);
+    if (a.rows <= 4) return launch_suffix_r<T, D, 4>(a, s);
+    return launch_suffix_r<T, D, 8>(a, s);
+}
+
+int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s) {
+    if (dtype == HYD_F16) {
+        if (D == 128) return launch_suffix_t<F16, 128>(a, s);
+        if (D == 64) return launch_suffix_t<F16, 64>(a, s);
+    } else {
+        if (D == 128) return launch_suffix_t<BF16, 128>(a, s);
+        if (D == 64) return launch_suffix_t<BF16, 64>(a, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace hyd

@@ -1,0 +1,176 @@
+/*
+ * hydragen_hip.h -- C ABI of libhydragen_hip.so: Hydragen's decomposed shared-prefix attention
+ * (prefix pass + suffix pass + log-sum-exp combine) as hand-written HIP kernels for gfx950
+ * (MI355X / CDNA4).
+ *
+ * This is the drop-in boundary for the reference's hot path.  Each entry point names the
+ * reference interface it replaces (file:line relative to ScalingIntelligence/hydragen):
+ *
+ *   hyd_prefix_attn_fwd     hydragen/flash.py:284-306  flash_attention        (K1, K2c)
+ *                           hydragen/flash.py:309-351  flash_attention_varlen (K1v)
+ *                           i.e. flash-attn 2.3.6 _flash_attn_forward/_flash_attn_varlen_forward
+ *                           as called from hydragen/attention.py:270,313,344
+ *   hyd_suffix_attn_fwd     hydragen/flash.py:163-281  flash_attention_seqlen
+ *                           (= xformers_stuff.py:189-428 _fwd_kernel_splitK + flash.py:76-160
+ *                           _splitK_reduce), optionally with attention.py:352 combine fused in
+ *   hyd_combine_lse         hydragen/attention.py:154-174 combine_lse (N partials; replaces both
+ *                           combine_lse_triton :105-151 and combine_lse_torch :21-43)
+ *   hyd_decode_attn_fused   hydragen/attention.py:177-354 hydragen_attention for the decode
+ *                           case (seq_lens given): all shared levels + suffix + combine
+ *   hyd_workspace_bytes     replaces the per-call torch.empty scratch of flash.py:199-204
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - the library never allocates device memory, never synchronises, holds no mutable global
+ *     state, and launches only on the hipStream_t passed in (as void*): every call is
+ *     HIP-graph-capture safe;
+ *   - launch geometry is derived from shapes only, never from device data;
+ *   - every call returns HYD_OK (0) or a negative error code; hyd_last_error_string() gives the
+ *     message for the calling thread's last failure;
+ *   - 16-bit dtypes: HYD_F16 (IEEE half) and HYD_BF16; accumulation, softmax and LSE are fp32.
+ *   - q/out are [B, nq, Hq, D] contiguous; K/V tensors are token-major with explicit element
+ *     strides and a contiguous head_dim; supported head_dim: 64, 128.
+ */
+#ifndef HYDRAGEN_HIP_H
+#define HYDRAGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYD_VERSION 100 /* 0.1.0 */
+#define HYD_MAX_LEVELS 8
+
+enum {
+    HYD_OK = 0,
+    HYD_ERR_BAD_ARG = -1,     /* null pointer, non-positive size, indivisible batch ...      */
+    HYD_ERR_UNSUPPORTED = -2, /* dtype / head_dim / row count the kernels do not implement    */
+    HYD_ERR_WORKSPACE = -3,   /* workspace missing or smaller than hyd_*_workspace_bytes says */
+    HYD_ERR_LAUNCH = -4       /* hipLaunchKernel reported an error                            */
+};
+
+enum { HYD_F16 = 0, HYD_BF16 = 1, HYD_F32 = 2 /* hyd_combine_lse only */ };
+
+/* LSE layouts: BQH = [B, nq, Hq] (what attention.py:276-280 re-lays flash's output into),
+ *              BHQ = [sb, Hq, (B/sb)*nq] (what flash-attn returns, flash.py:295-306). */
+enum { HYD_LSE_BQH = 0, HYD_LSE_BHQ = 1 };
+
+/* ------------------------------------------------------------------------------------------
+ * Prefix pass: batched-query attention of every query of a group against that group's single
+ * shared K/V, on the MFMA matrix cores.  Sequence b belongs to group b / (B/sb)
+ * (attention.py:264-268).  GQA: q-head h reads kv-head h / (Hq/Hkv).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hyd_prefix_params {
+    const void* q;               /* [B, nq, Hq, D]                                             */
+    const void* k;               /* group gi, token t, head h at k + gi*k_group_stride +       */
+    const void* v;               /*   t*k_tok_stride + h*k_head_stride (elements); D contiguous */
+    void* out;                   /* [B, nq, Hq, D] in dtype                                    */
+    float* lse;                  /* may be NULL; natural log, softmax scale included           */
+    const int32_t* cu_seqlens_k; /* NULL, or [sb+1]: group gi owns packed tokens               */
+                                 /*   [cu[gi], cu[gi+1]) of k/v (k_group_stride ignored)        */
+    const int32_t* cu_seqlens_q; /* NULL, or [sb+1] packed query tokens per group (then B is   */
+                                 /*   the total number of query tokens and nq must be 1)       */
+    void* workspace;             /* >= hyd_prefix_workspace_bytes(); may be NULL if that is 0  */
+    size_t workspace_bytes;
+    int64_t k_group_stride, k_tok_stride, k_head_stride;
+    int64_t v_group_stride, v_tok_stride, v_head_stride;
+    int32_t dtype;      /* HYD_F16 | HYD_BF16                                                  */
+    int32_t B, nq, Hq, Hkv, D;
+    int32_t sb;         /* number of groups (shared sequences); B % sb == 0                    */
+    int32_t kv_len;     /* keys per group; with cu_seqlens_k: the maximum over groups          */
+    int32_t max_q_len;  /* only with cu_seqlens_q: max query tokens per group                  */
+    int32_t causal;     /* 0 | 1 (bottom-right aligned: query i sees keys j <= i + kv - nq)    */
+    int32_t lse_layout; /* HYD_LSE_BQH | HYD_LSE_BHQ                                           */
+    int32_t num_splits; /* split-KV factor; 0 = choose from shapes                             */
+} hyd_prefix_params;
+
+size_t hyd_prefix_workspace_bytes(const hyd_prefix_params* p);
+int hyd_prefix_attn_fwd(const hyd_prefix_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Suffix pass: every query row of sequence b against the first seq_len[b] keys of b's own
+ * K/V (non-causal), one wavefront per (sequence, kv-head), HBM-bandwidth bound.  When
+ * n_partials > 0 the log-sum-exp merge with already-computed partial results (the prefix
+ * passes) is done in the epilogue and `out` is the final attention output.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hyd_partial {
+    const void* out;  /* [count][B, nq, Hq, D]; dtype, or fp32 when is_f32                      */
+    const float* lse; /* [count][B, nq, Hq]                                                     */
+    int32_t count;    /* number of stacked partials behind these pointers (split-KV slices)    */
+    int32_t is_f32;
+} hyd_partial;
+
+typedef struct hyd_suffix_params {
+    const void* q;              /* [B, nq, Hq, D]                                              */
+    const void* k;              /* sequence b, token t, head h at k + b*k_batch_stride +       */
+    const void* v;              /*   t*k_tok_stride + h*k_head_stride (elements)               */
+    void* out;                  /* [B, nq, Hq, D] in dtype                                     */
+    float* lse;                 /* [B, nq, Hq] or NULL; LSE of the suffix pass alone           */
+    const int32_t* seq_lens_i32; /* [B] or NULL                                                */
+    const int64_t* seq_lens_i64; /* [B] or NULL (the reference's callers hold int64:           */
+                                 /*   llama.py:569); both NULL = every sequence uses kv_len    */
+    int64_t k_batch_stride, k_tok_stride, k_head_stride;
+    int64_t v_batch_stride, v_tok_stride, v_head_stride;
+    int32_t dtype;
+    int32_t B, nq, Hq, Hkv, D;
+    int32_t kv_len;             /* allocated keys per sequence (Mk); lengths are clamped to it */
+    int32_t n_partials;         /* entries used in partials[]                                  */
+    hyd_partial partials[HYD_MAX_LEVELS];
+} hyd_suffix_params;
+
+int hyd_suffix_attn_fwd(const hyd_suffix_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * combine_lse for N partials (attention.py:21-43): out = sum_i out_i*exp(lse_i-m) / sum_i exp(lse_i-m).
+ * rows = B*nq*Hq.  `outs`/`lses` are HOST arrays of n device pointers.  dtype may be HYD_F32.
+ * out_lse (may be NULL) receives the merged LSE  m + log(sum_i exp(lse_i - m)).
+ * ------------------------------------------------------------------------------------------ */
+int hyd_combine_lse(const void* const* outs, const float* const* lses, int32_t n, int64_t rows, int32_t D,
+                    int32_t dtype, void* out, float* out_lse, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole decode-step operator: hydragen_attention with seq_lens given (attention.py:177-354):
+ * one prefix pass per shared level into the workspace, then the suffix pass with the merge
+ * fused into its epilogue.  With kv_len == 0 and one level the prefix result is written to
+ * `out` directly (attention.py:273-274).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hyd_level {
+    const void* k;
+    const void* v;
+    const int32_t* cu_seqlens_k; /* NULL for uniform levels                                   */
+    int64_t k_group_stride, k_tok_stride, k_head_stride;
+    int64_t v_group_stride, v_tok_stride, v_head_stride;
+    int32_t sb;                  /* shared sequences in this level                            */
+    int32_t kv_len;              /* uniform length, or max length when cu_seqlens_k != NULL   */
+} hyd_level;
+
+typedef struct hyd_decode_params {
+    hyd_suffix_params suffix;    /* q, unique k/v, seq_lens, out; n_partials/partials ignored */
+    hyd_level levels[HYD_MAX_LEVELS];
+    int32_t n_levels;
+    int32_t reserved;
+    void* workspace;             /* >= hyd_decode_workspace_bytes()                           */
+    size_t workspace_bytes;
+} hyd_decode_params;
+
+size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);
+int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
+
+/* Upper bound helper mirroring SURVEY 8b's `hyd_workspace_bytes(shape...)`: bytes that
+ * hyd_decode_attn_fused needs for n_levels uniform levels of the given shapes. */
+size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32_t D, int32_t n_levels,
+                           const int32_t* level_sb, const int32_t* level_kv_len);
+
+int hyd_version(void);
+const char* hyd_last_error_string(void);
+
+/* Diagnostics used by tests/bench: the split-KV factor and grid the prefix pass would use. */
+int hyd_prefix_plan(const hyd_prefix_params* p, int32_t* num_splits, int32_t* grid, int32_t* split_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRAGEN_HIP_H */

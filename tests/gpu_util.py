@@ -1,0 +1,49 @@
+"""Helpers for the -m gpu parity tests: numpy case -> torch CUDA tensors -> hydragen_amd call."""
+import numpy as np
+import torch
+
+TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+# Tolerances.  fp16: the reference's own bar (tests/test_attention.py:36-38,185).
+# bf16 has 3 fewer mantissa bits than fp16 -> 8x the absolute bound; mean relative bound stated
+# against the float64 oracle on identical (bf16-rounded) inputs.
+ATOL = {"f16": 2e-3, "bf16": 1.6e-2}
+RTOL_MEAN = {"f16": 5e-3, "bf16": 1e-2}
+
+
+def dev(x, dtype=None, device="cuda:0"):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(TORCH_DT[dtype])
+    return t.to(device)
+
+
+def case_to_device(case):
+    dt = case["dtype"]
+    d = dict(
+        q=dev(case["q"], dt), k=dev(case["k"], dt), v=dev(case["v"], dt),
+        shared_ks=[dev(x, dt) for x in case["shared_ks"]],
+        shared_vs=[dev(x, dt) for x in case["shared_vs"]],
+        shared_cu_seq_lens=[None if c is None else dev(c) for c in case["shared_cu_seq_lens"]],
+        shared_max_seq_lens=case["shared_max_seq_lens"],
+        use_varlens=case["use_varlens"],
+        seq_lens=None if case["seq_lens"] is None else dev(case["seq_lens"]),
+    )
+    return d
+
+
+def rdiff(a, b, eps=1e-8):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return 2 * np.abs(a - b) / (np.abs(a) + np.abs(b) + eps)
+
+
+def assert_close(got, want, dtype, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite output"
+    err = np.abs(got - want).max()
+    mrd = rdiff(got, want).mean()
+    assert err <= ATOL[dtype] and mrd <= RTOL_MEAN[dtype], f"{what}: max abs {err:.3e} mean rdiff {mrd:.3e}"
+    return err, mrd

@@ -1,0 +1,121 @@
+"""-m "not gpu": the C-ABI library loads, exports every symbol include/hydragen_hip.h declares, and its
+host-side logic (validation, planning, workspace sizing, error strings) behaves -- no compute calls."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from hydragen_amd import _lib
+from hydragen_amd._lib import DecodeParams, PrefixParams, SuffixParams
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_exports_match_header():
+    lib = _lib.load()
+    header = (REPO / "include" / "hydragen_hip.h").read_text()
+    declared = set(re.findall(r"\b(hyd_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    assert lib.hyd_version() == 100
+
+
+def test_struct_layout_matches_c():
+    """ctypes mirrors must have the C compiler's sizes (checked against a gcc build of the header)."""
+    import subprocess, tempfile
+    src = '#include "hydragen_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(hyd_prefix_params), sizeof(hyd_partial), sizeof(hyd_suffix_params), sizeof(hyd_level), sizeof(hyd_decode_params));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "s.c").write_text(src)
+        subprocess.check_call(["gcc", "-I", str(REPO / "include"), str(Path(d) / "s.c"), "-o", str(Path(d) / "s")])
+        sizes = list(map(int, subprocess.check_output([str(Path(d) / "s")]).split()))
+    assert sizes == [C.sizeof(PrefixParams), C.sizeof(_lib.Partial), C.sizeof(SuffixParams), C.sizeof(_lib.Level),
+                     C.sizeof(DecodeParams)]
+
+
+def _prefix(**kw):
+    p = PrefixParams()
+    p.dtype, p.B, p.nq, p.Hq, p.Hkv, p.D, p.sb, p.kv_len = 1, 1024, 1, 32, 32, 128, 1, 2048
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _plan(p):
+    lib = _lib.load()
+    ns, grid, sl = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.hyd_prefix_plan(C.byref(p), C.byref(ns), C.byref(grid), C.byref(sl))
+    return rc, ns.value, grid.value, sl.value
+
+
+def test_plan_c2_fills_the_chip_without_split():
+    rc, ns, grid, sl = _plan(_prefix())
+    assert (rc, ns, grid) == (0, 1, 256)  # 32 heads x 8 row blocks of 128 queries = 256 CUs
+    assert _lib.load().hyd_prefix_workspace_bytes(C.byref(_prefix())) == 0
+
+
+def test_plan_c3_splits_kv():
+    # B=64, 32q/8kv, P=16384: 8 heads x 2 row blocks = 16 units -> split-KV (SURVEY 5 'build implication')
+    p = _prefix(B=64, Hq=32, Hkv=8, kv_len=16384)
+    rc, ns, grid, sl = _plan(p)
+    assert rc == 0 and ns > 1 and grid == 16 * ns and sl % 128 == 0 and ns * sl >= 16384
+    assert _lib.load().hyd_prefix_workspace_bytes(C.byref(p)) >= ns * 64 * 32 * 128 * 4
+
+
+@pytest.mark.parametrize("kw,code,frag", [
+    (dict(D=96), -2, "head_dim"),
+    (dict(dtype=2), -2, "dtype"),
+    (dict(B=1000, sb=3), -1, "not divisible"),
+    (dict(Hq=32, Hkv=5), -1, "not divisible"),
+    (dict(B=0), -1, "non-positive"),
+])
+def test_bad_arguments_are_rejected_with_a_message(kw, code, frag):
+    lib = _lib.load()
+    rc, *_ = _plan(_prefix(**kw))
+    assert rc == code
+    assert frag in lib.hyd_last_error_string().decode()
+    # the launch entry point refuses the same arguments before touching the device
+    assert lib.hyd_prefix_attn_fwd(C.byref(_prefix(**kw)), None) == code
+    with pytest.raises((ValueError, NotImplementedError)):
+        _lib.check(code)
+
+
+def test_null_and_misaligned_pointers_rejected():
+    lib = _lib.load()
+    p = _prefix()
+    assert lib.hyd_prefix_attn_fwd(C.byref(p), None) == -1 and "null" in lib.hyd_last_error_string().decode()
+    s = SuffixParams()
+    s.dtype, s.B, s.nq, s.Hq, s.Hkv, s.D, s.kv_len = 1, 4, 1, 8, 8, 128, 16
+    s.q = 0x1008
+    assert lib.hyd_suffix_attn_fwd(C.byref(s), None) == -1 and "aligned" in lib.hyd_last_error_string().decode()
+
+
+def test_decode_workspace_accounting():
+    lib = _lib.load()
+    sb = (C.c_int32 * 2)(1, 32)
+    ln = (C.c_int32 * 2)(1024, 64)
+    rows = 1024 * 32
+    # C4: two levels, both fill the chip -> one bf16 slice + one fp32 LSE vector per level
+    want = 2 * (rows * 128 * 2 + rows * 4)
+    assert lib.hyd_workspace_bytes(1024, 1, 32, 32, 128, 2, sb, ln) == want
+    d = DecodeParams()
+    d.suffix.dtype, d.suffix.B, d.suffix.nq, d.suffix.Hq, d.suffix.Hkv, d.suffix.D = 1, 1024, 1, 32, 32, 128
+    d.n_levels = 9
+    assert lib.hyd_decode_attn_fused(C.byref(d), None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from hydragen_amd.attention import hydragen_attention_nopad
+    q = torch.zeros(2, 1, 4, 64, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hydragen_attention_nopad(q, q, q, [q[:1]], [q[:1]])
+
+
+def test_product_sources_never_touch_the_oracle():
+    for path in list((REPO / "hydragen_amd").rglob("*.py")) + list((REPO / "hydragen_amd").rglob("*.hip")) + \
+            list((REPO / "hydragen_amd").rglob("*.h")):
+        txt = path.read_text()
+        assert "oracle" not in txt.replace("no CPU oracle", "").replace("or the CPU oracle", ""), path
