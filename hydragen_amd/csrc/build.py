@@ -19,6 +19,8 @@ HEADERS = ["hyd_common.h", "hyd_kernels.h", "../../include/hydragen_hip.h"]
 LIB = HERE / "libhydragen_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("HYD_ABLATION_BUILD"):  # development only: compiles the timing-ablation kernel variants
+    FLAGS.append("-DHYD_ABLATION_BUILD")
 
 
 def _stale(target: Path, deps) -> bool:

@@ -16,8 +16,10 @@
 //                                      row-major V tile, B = P^T converted in registers; the
 //                                      contraction index is permuted so no cross-lane moves are needed)
 //   the two key halves keep independent (m, l, O) and are merged through LDS at the end.
-// K/V tiles are staged global -> registers -> LDS with the loads for tile t+1 issued before the
-// compute on tile t.  HBM/L2: blocks that share a (group, kv-head) are remapped onto one XCD.
+// K/V tiles go global -> LDS by DMA (global_load_lds) into a double buffer: tile t+1 lands while tile t
+// is computed, one barrier per tile.  HBM/L2: blocks that share a (group, kv-head) are remapped onto one XCD.
+#include <type_traits>
+
 #include "hyd_kernels.h"
 
 namespace hyd {
@@ -34,12 +36,50 @@ __device__ __forceinline__ int vswz(int row, int ch) {
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-__device__ __forceinline__ u32x2 lds_tr16(const char* p) {
-    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+__device__ __forceinline__ u32x2 lds_tr16(unsigned lds_byte_addr) {
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uintptr_t)lds_byte_addr);
     return __builtin_bit_cast(u32x2, t);
 }
 
-template <typename T, int D, bool CAUSAL>
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB)
+// (dst wave-uniform).  Issued from inline asm on purpose: hipcc then does not know an LDS write is in
+// flight, so it neither drains it (vmcnt(0)) in front of the transposing reads of the current tile nor
+// counts it; the tile loop waits for it explicitly (dma_wait_all) right before its barrier.
+__device__ __forceinline__ void dma16(const char* gsrc, const char* lds_dst) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(l)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// 2*NDB transposing reads (one 16-key slot of the V^T operand) issued from inline asm with immediate
+// offsets; results are only valid after the matching tr_retire().
+template <int NDB, int OFF0, int OFF1>
+__device__ __forceinline__ void tr_issue(const unsigned (&va)[NDB], u32x2 (&r)[2 * NDB]) {
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(r[2 * db]), "=&v"(r[2 * db + 1])
+                     : "v"(va[db]), "i"(OFF0), "i"(OFF1));
+}
+// wait until at most PENDING LDS operations are outstanding; names the registers it retires so that
+// nothing consumes them early (LDS data returns in order), then pins the order for the MFMAs (rule 18).
+template <int NDB, int PENDING>
+__device__ __forceinline__ void tr_retire(u32x2 (&c)[2 * NDB]) {
+    if constexpr (NDB == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
+                     "+v"(c[6]), "+v"(c[7]) : "i"(PENDING));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "i"(PENDING));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ABL: development-only ablation mask (bit0 no in-loop DMA, bit1 no QK, bit2 no softmax, bit3 no PV);
+// only ABL = 0 is ever used for results.
+template <typename T, int D, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
     using TR = Traits<T>;
     constexpr int RB = D * 2;            // bytes per K/V row
@@ -48,14 +88,15 @@ __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
     constexpr int NDB = D / 32;          // 32-wide d blocks of O^T
     constexpr int NLD = (128 * CPR) / 512;  // 16-byte chunks per thread per tensor per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                     // [128 keys][RB], swizzled
-    char* Vs = smem + 128 * RB;          // [128 keys][RB], swizzled
-    float* mlbuf = reinterpret_cast<float*>(smem + 256 * RB);  // [4][2][64]
+    float* mlbuf = reinterpret_cast<float*>(smem + 512 * RB);  // [4][2][64], after the K/V buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rw = wave & 3, kg = wave >> 2;
+    // compute roles: rw = 32-row sub-block, kg = key half.  DMA roles (kgd) are fixed by wave index.
+    const int kg = (a.dbg & 16) ? (wave & 1) : (wave >> 2);
+    const int rw = (a.dbg & 16) ? (wave >> 1) : (wave & 3);
+    const int kgd = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- which (group, kv head, split, row block) ------------------------------------------
@@ -124,41 +165,95 @@ __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
         }
     }
 
-    // ---- per-lane LDS addresses (bytes) ---------------------------------------------------
+    // ---- LDS map (bytes): KA[2] | KB[2] | V[2] | mlbuf ----------------------------------------------
+    // KA[i]: rows 0..63 of K tile (kg = 0 waves), KB[i]: rows 64..127 (kg = 1 waves), V[i]: 128 rows.
+    constexpr int KH_BYTES = 64 * RB;
+    constexpr int V_BYTES = 128 * RB;
+    constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = 4 * KH_BYTES;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef const __attribute__((address_space(3))) char* lptr_c;
+
+    // ---- per-lane LDS byte addresses; tile/buffer/row-block offsets are compile-time immediates -------
     const int ksw = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
     const int kx = hi ^ ksw;
-    int kaddr[NC];
+    unsigned kaddr[NC];  // K fragment c of row l31, relative to the start of a 64-row half tile
 #pragma unroll
-    for (int c = 0; c < NC; ++c) kaddr[c] = (kg * 64 + l31) * RB + (((2 * c) ^ kx) << 4);
+    for (int c = 0; c < NC; ++c) kaddr[c] = (unsigned)(uintptr_t)(lptr_c)(smem + l31 * RB + (((2 * c) ^ kx) << 4));
     const int i16 = lane & 15, g16 = lane >> 4;
     const int vsw = D == 128 ? (i16 >> 2) : ((i16 >> 3) & 1);
-    int vaddr[NDB];
+    unsigned vaddr[NDB];  // V^T fragment address inside V buffer 0 for key slot 0
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
-        vaddr[db] = (kg * 64 + 4 * hi + (i16 >> 2)) * RB + ((db ^ vsw) << 6) + 32 * (g16 & 1) + 8 * (i16 & 3);
+        vaddr[db] = (unsigned)(uintptr_t)(lptr_c)(smem + V_OFF + (kg * 64 + 4 * hi + (i16 >> 2)) * RB +
+                                                  ((db ^ vsw) << 6) + 32 * (g16 & 1) + 8 * (i16 & 3));
 
-    // ---- staging: thread -> (tile row, 16B chunk) -----------------------------------------
-    u32x4 kreg[NLD], vreg[NLD];
-    auto gload = [&](int kt) {
+    // ---- staging: global -> LDS DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction) -------
+    // The LDS image of a wave instruction is lane-linear (base + lane*16), so the XOR swizzles are
+    // applied to the per-lane SOURCE chunk (they are involutions inside a row).  Wave w fills rows
+    // [16w, 16w+16) of the 128-row K image (waves 0-3 -> KA half, waves 4-7 -> KB half) and of the V tile.
+    // Per-lane byte offsets inside a tile are fixed; the tile base is wave-uniform.
+    constexpr int RPI = 1024 / RB;  // tile rows per wave instruction
+    const int drow = (lane * 16) / RB;                // row inside the instruction
+    const int dcp = ((lane * 16) % RB) >> 4;          // 16-byte slot inside the row (LDS side)
+    unsigned koff[NLD], voff[NLD];  // < 128 rows * token stride * 2 B: always fits 32 bits
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int c = tid + 512 * i;
-            const int row = c / CPR, ch = c % CPR;
-            // unpredicated loads: rows past the end re-read the last valid key; their scores are masked to
-            // -inf so they contribute exactly 0
-            const int key = min(kbeg + kt * 128 + row, kend - 1);
-            kreg[i] = *reinterpret_cast<const u32x4*>(k16 + (int64_t)key * a.k_ts + ch * 8);
-            vreg[i] = *reinterpret_cast<const u32x4*>(v16 + (int64_t)key * a.v_ts + ch * 8);
+    for (int i = 0; i < NLD; ++i) {
+        const int row = (wave * NLD + i) * RPI + drow;  // row of the 128-row tile
+        const int kch = D == 128 ? (dcp ^ (row & 15)) : (dcp ^ ((row >> 1) & 7));
+        const int vs_ = D == 128 ? (row & 3) : ((row >> 1) & 1);
+        const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
+        koff[i] = (unsigned)(((int64_t)row * a.k_ts + kch * 8) * 2);
+        voff[i] = (unsigned)(((int64_t)row * a.v_ts + vch * 8) * 2);
+    }
+    const char* kbase = reinterpret_cast<const char*>(k16) + (int64_t)kbeg * a.k_ts * 2;
+    const char* vbase = reinterpret_cast<const char*>(v16) + (int64_t)kbeg * a.v_ts * 2;
+    const int nkeys = kend - kbeg;
+    // One DMA instruction ("piece") at a time, so the tile loop can spread them between its MFMAs: issued
+    // back to back they fill the VMEM queue and the wave sits at issue until the address path has taken
+    // them all (the fetch then runs in series with the compute instead of underneath it).
+    // pieces [0, NLD): K half tile of tile tk (or none if tk < 0); pieces [NLD, 2*NLD): V tile tv.
+    int dma_tk = -1, dma_tv = -1;
+    auto dma_piece_c = [&](auto J_C) {
+        constexpr int j = decltype(J_C)::value;
+        if constexpr (j < NLD) {
+            constexpr int i = j;
+            const int tk = dma_tk;
+            if (tk < 0) return;
+            char* Kd = smem + (kgd ? KB_OFF : KA_OFF) + (tk & 1) * KH_BYTES + (wave & 3) * NLD * 1024;
+            const char* tb = kbase + (int64_t)tk * 128 * a.k_ts * 2;  // wave-uniform
+            // last, partial tile: rows past the end re-read the last valid key (scores masked)
+            const int over = (tk * 128 + 128 <= nkeys) ? 0 : max(0, tk * 128 + (wave * NLD + i) * RPI + drow - (nkeys - 1));
+            dma16(tb + koff[i] - (int64_t)over * a.k_ts * 2, Kd + i * 1024);
+        } else if constexpr (j < 2 * NLD) {
+            constexpr int i = j - NLD;
+            const int tv = dma_tv;
+            if (tv < 0) return;
+            char* Vd = smem + V_OFF + (tv & 1) * V_BYTES + wave * NLD * 1024;
+            const char* tb = vbase + (int64_t)tv * 128 * a.v_ts * 2;
+            const int over = (tv * 128 + 128 <= nkeys) ? 0 : max(0, tv * 128 + (wave * NLD + i) * RPI + drow - (nkeys - 1));
+            dma16(tb + voff[i] - (int64_t)over * a.v_ts * 2, Vd + i * 1024);
         }
     };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int c = tid + 512 * i;
-            const int row = c / CPR, ch = c % CPR;
-            *reinterpret_cast<u32x4*>(Ks + row * RB + (kswz<D>(row, ch) << 4)) = kreg[i];
-            *reinterpret_cast<u32x4*>(Vs + row * RB + (vswz<D>(row, ch) << 4)) = vreg[i];
+    auto dma_piece = [&](int j) {  // j is a constant after unrolling; the switch keeps every index static
+        using std::integral_constant;
+        switch (j) {
+            case 0: dma_piece_c(integral_constant<int, 0>{}); break;
+            case 1: dma_piece_c(integral_constant<int, 1>{}); break;
+            case 2: dma_piece_c(integral_constant<int, 2>{}); break;
+            case 3: dma_piece_c(integral_constant<int, 3>{}); break;
+            case 4: dma_piece_c(integral_constant<int, 4>{}); break;
+            case 5: dma_piece_c(integral_constant<int, 5>{}); break;
+            case 6: dma_piece_c(integral_constant<int, 6>{}); break;
+            case 7: dma_piece_c(integral_constant<int, 7>{}); break;
+            default: break;
         }
+    };
+    auto dma = [&](int tk, int tv) {  // whole tile at once (prologue)
+        dma_tk = tk;
+        dma_tv = tv;
+#pragma unroll
+        for (int j = 0; j < 2 * NLD; ++j) dma_piece(j);
     };
 
     f32x16 o[NDB];
@@ -168,94 +263,171 @@ __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sc = a.scale_log2e;
+    f32x16 s[2];
+    u32x4 pf[4];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    if (nkt > 0) {
-        gload(0);
-        sstore();
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) gload(kt + 1);
-
-        const int kw0 = kbeg + kt * 128 + kg * 64;  // first key of this wave's half tile
-        if (kw0 < kend) {
-            // ---- S^T = K Q^T -----------------------------------------------------------------
-            f32x16 s[2];
+    // ---- the three phases of a 64-key half tile -------------------------------------------------------
+    // S^T = K Q^T.  K fragments are prefetched PD steps ahead of the MFMA that consumes them (hipcc
+    // otherwise serialises ds_read -> s_waitcnt -> mfma, exposing the LDS latency 16 times per tile).
+    // KOFF = compile-time byte offset of the half tile inside LDS.
+    auto qk_phase = [&](auto KOFF_C, auto P0_C) {
+        constexpr int KOFF = decltype(KOFF_C)::value;
+        constexpr int P0 = decltype(P0_C)::value;  // first DMA piece to issue here, or -1 for none
+        constexpr int PD = 4;
+        u32x4 kfr[PD];
+        // step i -> (c = i / 2, kb = i % 2): consecutive MFMAs alternate between the two accumulators (an
+        // extra issue slot between two MFMAs on the SAME accumulator costs ~40 cycles, MI355X_MICROARCH.md)
+        auto ldk = [&](int i) -> u32x4 {
+            return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
+                (uintptr_t)(kaddr[i / 2] + KOFF + (i % 2) * 32 * RB));
+        };
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+        for (int i = 0; i < PD; ++i) kfr[i] = ldk(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + kaddr[c] + kb * 32 * RB);
-                    s[kb] = TR::mfma32(kf, qf[c], s[kb]);
-                }
-            }
-            // ---- masking (tail of the key range, causal diagonal) ------------------------------
-            int lim = kend - 1;
-            if (CAUSAL) lim = min(lim, row_lim);
-            const bool need_mask =
-                (kw0 + 64 > kend) || (CAUSAL && __builtin_amdgcn_ballot_w64(row_lim < kw0 + 63) != 0ull);
-            if (need_mask) {
-                const int lr = lim - kw0 - 4 * hi;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (kb * 32 + 8 * (i >> 2) + (i & 3) > lr) s[kb][i] = -INFINITY;
-            }
-            // ---- online softmax (base 2) -------------------------------------------------------
-            float tmax = s[0][0];
+        for (int i = 0; i < 2 * NC; ++i) {
+            const int kb = i % 2, c = i / 2;
+            s[kb] = TR::mfma32(kfr[i % PD], qf[c], c == 0 ? zero16 : s[kb]);
+            if (i + PD < 2 * NC) kfr[i % PD] = ldk(i + PD);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            constexpr int EVERY = (2 * NC) / NLD;
+            if (P0 >= 0 && !(ABL & 1) && (i % EVERY) == EVERY - 1) dma_piece(P0 + i / EVERY);
+        }
+    };
+    // masking + online softmax (base 2) + P^T fragments; whole-vector arithmetic so that hipcc emits the
+    // packed fp32 forms (v_pk_fma_f32 / v_pk_add_f32) and v_max3_f32: this phase is VALU-issue bound.
+    auto sm_phase = [&](int kw0) {
+        int lim = kend - 1;
+        if (CAUSAL) lim = min(lim, row_lim);
+        const bool need_mask =
+            (kw0 + 64 > kend) || (CAUSAL && __builtin_amdgcn_ballot_w64(row_lim < kw0 + 63) != 0ull);
+        if (need_mask) {
+            const int lr = lim - kw0 - 4 * hi;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[kb][i]);
-            tmax = pair_max(tmax);
-            const float m_new = fmaxf(m_run, tmax * sc);
-            const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - msafe);
-            float rs = 0.f;
+                for (int i = 0; i < 16; ++i)
+                    if (kb * 32 + 8 * (i >> 2) + (i & 3) > lr) s[kb][i] = -INFINITY;
+        }
+        float tmax = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(fmaxf(tmax, s[0][i]), s[1][i]);
+        tmax = pair_max(tmax);
+        const float m_new = fmaxf(m_run, tmax * sc);
+        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - msafe);
+        s[0] = s[0] * sc - msafe;
+        s[1] = s[1] * sc - msafe;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = fast_exp2(__builtin_fmaf(s[kb][i], sc, -msafe));
-                    s[kb][i] = p;
-                    rs += p;
-                }
-            l_run = l_run * alpha + rs;
-            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
+        for (int i = 0; i < 16; ++i) {
+            s[0][i] = fast_exp2(s[0][i]);
+            s[1][i] = fast_exp2(s[1][i]);
+        }
+        const f32x16 t16 = s[0] + s[1];
+        const f32x8 t8 = t16.lo + t16.hi;
+        const f32x4 t4 = t8.lo + t8.hi;
+        const f32x2 t2 = t4.lo + t4.hi;
+        l_run = l_run * alpha + (t2[0] + t2[1]);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {
 #pragma unroll
-                for (int db = 0; db < NDB; ++db) o[db] *= alpha;
+            for (int db = 0; db < NDB; ++db) o[db] *= alpha;
+        }
+        m_run = m_new;
+        // slot ks (16 keys) <- regs [8*(ks&1), +8) of block ks>>1
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kb = ks >> 1, b0 = 8 * (ks & 1);
+            pf[ks][0] = TR::pack2(s[kb][b0 + 0], s[kb][b0 + 1]);
+            pf[ks][1] = TR::pack2(s[kb][b0 + 2], s[kb][b0 + 3]);
+            pf[ks][2] = TR::pack2(s[kb][b0 + 4], s[kb][b0 + 5]);
+            pf[ks][3] = TR::pack2(s[kb][b0 + 6], s[kb][b0 + 7]);
+        }
+    };
+    // O^T += V^T P^T (V^T fragments by the transposing LDS read; hipcc pipelines them with counted waits).
+    // VOFF = compile-time byte offset of the V buffer relative to V buffer 0.
+    auto pv_phase = [&](auto VOFF_C, auto P0_C) {
+        constexpr int VOFF = decltype(VOFF_C)::value;
+        constexpr int P0 = decltype(P0_C)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const u32x2 t0 = lds_tr16(vaddr[db] + VOFF + (16 * ks) * RB);
+                const u32x2 t1 = lds_tr16(vaddr[db] + VOFF + (16 * ks + 8) * RB);
+                const u32x4 vf = {t0[0], t0[1], t1[0], t1[1]};
+                o[db] = TR::mfma32(vf, pf[ks], o[db]);
             }
-            m_run = m_new;
-            // ---- P^T fragments: slot ks (16 keys) <- regs [8*(ks&1), +8) of block ks>>1 -----------
-            u32x4 pf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int kb = ks >> 1, b0 = 8 * (ks & 1);
-                pf[ks][0] = TR::pack2(s[kb][b0 + 0], s[kb][b0 + 1]);
-                pf[ks][1] = TR::pack2(s[kb][b0 + 2], s[kb][b0 + 3]);
-                pf[ks][2] = TR::pack2(s[kb][b0 + 4], s[kb][b0 + 5]);
-                pf[ks][3] = TR::pack2(s[kb][b0 + 6], s[kb][b0 + 7]);
-            }
-            // ---- O^T += V^T P^T ----------------------------------------------------------------
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) {
-                    const u32x2 t0 = lds_tr16(Vs + vaddr[db] + (16 * ks) * RB);
-                    const u32x2 t1 = lds_tr16(Vs + vaddr[db] + (16 * ks + 8) * RB);
-                    const u32x4 vf = {t0[0], t0[1], t1[0], t1[1]};
-                    o[db] = TR::mfma32(vf, pf[ks], o[db]);
-                }
+            if (P0 >= 0 && !(ABL & 1)) {  // spread NLD DMA pieces over the 4 key slots
+                if (NLD == 4) dma_piece(P0 + ks);
+                else if (ks % 2 == 1) dma_piece(P0 + ks / 2);
             }
         }
-        __syncthreads();
-        if (more) sstore();
-        __syncthreads();
+    };
+
+    // ---- pipeline ---------------------------------------------------------------------------------
+    // The two waves of a SIMD (same rows, kg = 0 / 1) run the phases in different orders so that one is
+    // on the matrix pipe while the other is in the softmax VALU phase:
+    //     kg = 0 :  QK(t)   SM(t)  PV(t)     | barrier
+    //     kg = 1 :  SM(t)   PV(t)  QK(t+1)   | barrier     (its half of the K stream runs one tile ahead)
+    // The tile loop is unrolled by two so every LDS buffer offset is an instruction immediate.
+    using std::integral_constant;
+    if (nkt > 0) {
+        dma(0, 0);
+        if (kgd == 1 && nkt > 1) dma(1, -1);
+    }
+    // Make the compiler wait for the Q fragments here, not (conservatively, with vmcnt(0)) inside the
+    // loop where it would also drain the DMA of the next K/V tiles.
+#pragma unroll
+    for (int c = 0; c < NC; ++c) asm volatile("" ::"v"(qf[c]));
+    dma_wait_all();
+    __syncthreads();
+    if (kg == 1 && nkt > 0 && kbeg + 64 < kend) qk_phase(integral_constant<int, KB_OFF>{}, integral_constant<int, -1>{});
+    __syncthreads();  // KB[0] is re-filled (tile 2) by the first loop iteration
+
+    if (kg == 0) {
+        auto step = [&](auto PAR_C, int kt) {
+            constexpr int par = decltype(PAR_C)::value;
+            dma_tv = kt + 1 < nkt ? kt + 1 : -1;
+            dma_tk = kgd == 0 ? dma_tv : (kt + 2 < nkt ? kt + 2 : -1);
+            const int kw0 = kbeg + kt * 128;  // always < kend for kg = 0
+            if constexpr (!(ABL & 2)) qk_phase(integral_constant<int, KA_OFF + par * KH_BYTES>{}, integral_constant<int, 0>{});
+            if constexpr (!(ABL & 4)) sm_phase(kw0);
+            if constexpr (!(ABL & 8)) pv_phase(integral_constant<int, par * V_BYTES>{}, integral_constant<int, NLD>{});
+            dma_wait_all();
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nkt; kt += 2) {
+            step(integral_constant<int, 0>{}, kt);
+            if (kt + 1 < nkt) step(integral_constant<int, 1>{}, kt + 1);
+        }
+    } else {
+        auto step = [&](auto PAR_C, int kt) {
+            constexpr int par = decltype(PAR_C)::value;
+            dma_tv = kt + 1 < nkt ? kt + 1 : -1;
+            dma_tk = kgd == 0 ? dma_tv : (kt + 2 < nkt ? kt + 2 : -1);
+            const int kw0 = kbeg + kt * 128 + 64;
+            if (kw0 < kend) {
+                if constexpr (!(ABL & 4)) sm_phase(kw0);
+                if constexpr (!(ABL & 8)) pv_phase(integral_constant<int, par * V_BYTES>{}, integral_constant<int, NLD>{});
+            } else if constexpr (!(ABL & 1)) {
+#pragma unroll
+                for (int j = NLD; j < 2 * NLD; ++j) dma_piece(j);
+            }
+            if (kt + 1 < nkt && kw0 + 128 < kend && !(ABL & 2)) {
+                qk_phase(integral_constant<int, KB_OFF + (par ^ 1) * KH_BYTES>{}, integral_constant<int, 0>{});
+            } else if constexpr (!(ABL & 1)) {
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) dma_piece(j);
+            }
+            dma_wait_all();
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nkt; kt += 2) {
+            step(integral_constant<int, 0>{}, kt);
+            if (kt + 1 < nkt) step(integral_constant<int, 1>{}, kt + 1);
+        }
     }
 
     // ---- merge the two key halves through LDS, normalise, store --------------------------------
@@ -313,10 +485,10 @@ __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
     }
 }
 
-template <typename T, int D, bool CAUSAL>
+template <typename T, int D, bool CAUSAL, int ABL = 0>
 static int launch_prefix_t(const PrefixArgs& a, int grid, hipStream_t s) {
-    constexpr size_t lds = 256 * (D * 2) + 4 * 128 * sizeof(float);
-    auto kern = prefix_attn_kernel<T, D, CAUSAL>;
+    constexpr size_t lds = 2 * 256 * (D * 2) + 4 * 128 * sizeof(float);
+    auto kern = prefix_attn_kernel<T, D, CAUSAL, ABL>;
     static bool attr_set = false;  // idempotent; value never changes
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -328,6 +500,16 @@ static int launch_prefix_t(const PrefixArgs& a, int grid, hipStream_t s) {
 }
 
 int launch_prefix(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
+#ifdef HYD_ABLATION_BUILD
+    if (a.dbg && dtype == HYD_BF16 && D == 128 && !causal) {
+        switch (a.dbg) {
+#define HYD_ABL(N) case N: return launch_prefix_t<BF16, 128, false, N>(a, grid, s);
+            HYD_ABL(1) HYD_ABL(3) HYD_ABL(5) HYD_ABL(7) HYD_ABL(9) HYD_ABL(11) HYD_ABL(13) HYD_ABL(15) HYD_ABL(14)
+#undef HYD_ABL
+            default: break;
+        }
+    }
+#endif
 #define HYD_DISPATCH(TT, DD)                                                    \
     return causal ? launch_prefix_t<TT, DD, true>(a, grid, s) : launch_prefix_t<TT, DD, false>(a, grid, s)
     if (dtype == HYD_F16) {
