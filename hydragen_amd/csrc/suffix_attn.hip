@@ -26,6 +26,17 @@ __device__ __forceinline__ void widen8(const u32x4& v, float (&f)[8]) {
     }
 }
 
+// tell hipcc a pointer is wave-uniform (it is: derived from blockIdx and the wave index) so that it
+// lives in SGPRs and loads take the base + 32-bit-offset form
+typedef const __attribute__((address_space(1))) char* gchar_p;
+typedef const __attribute__((address_space(1))) u32x4* gu32x4_p;
+__device__ __forceinline__ gchar_p uniform_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gchar_p)(((uint64_t)hi << 32) | lo);
+}
+
 // merge (m, l, acc) state pairs; all values in base-2 domain
 __device__ __forceinline__ void merge_state(float& m, float& l, float (&acc)[8], float m2, float l2,
                                             const float (&acc2)[8]) {
@@ -39,11 +50,11 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float (&acc)[8],
 }
 
 template <typename T, int D, int R, int WPU>
-__global__ __launch_bounds__(256) void suffix_attn_kernel(const SuffixArgs a) {
+__global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int LPK = D / 8;    // lanes per key row
     constexpr int KPI = 64 / LPK; // keys per wave instruction
-    constexpr int U = (R <= 2) ? 8 : 4;  // key iterations in flight
+    constexpr int U = 4;  // key iterations in flight per wave (x2 tensors x 1 KiB); occupancy supplies the rest
     __shared__ float xbuf[WPU > 1 ? (WPU - 1) * R * (2 + D) : 1];
 
     const int tid = threadIdx.x;
@@ -76,9 +87,31 @@ __global__ __launch_bounds__(256) void suffix_attn_kernel(const SuffixArgs a) {
             qp[r] = z;
         }
     }
+    // ---- prefetch the first partial (the usual single prefix level) for the row this lane group will
+    // finish in the epilogue, so its HBM latency overlaps the K/V stream instead of following it -----
+    constexpr int RPG = (R + KPI - 1) / KPI;  // epilogue rows per lane group
+    float pl0[RPG];
+    u32x4 po0[RPG];
+    const bool pre0 = a.n_partials > 0 && !a.partials[0].is_f32;
+#pragma unroll
+    for (int j = 0; j < RPG; ++j) {
+        const int r = ks + j * KPI;
+        const int row = row0 + r;
+        pl0[j] = 0.f;
+        po0[j] = u32x4{0u, 0u, 0u, 0u};
+        if (pre0 && r < R && row < a.rows) {
+            const int iq = row / a.g, gq = row % a.g;
+            const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;
+            pl0[j] = a.partials[0].lse[ridx];
+            po0[j] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.partials[0].out) + ridx * D + sub * 8);
+        }
+    }
 
-    const uint16_t* kb_ = static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs + sub * 8;
-    const uint16_t* vb_ = static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs + sub * 8;
+    // wave-uniform unit base (scalar registers) + 32-bit per-lane byte offsets -> SADDR-form loads
+    const char* kb_ = reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs);
+    const char* vb_ = reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs);
+    const gchar_p kbu = uniform_ptr(kb_), vbu = uniform_ptr(vb_);
+    const unsigned krs = (unsigned)(a.k_ts * 2), vrs = (unsigned)(a.v_ts * 2);  // token stride in bytes
 
     float m[R], l[R], acc[R][8];
 #pragma unroll
@@ -101,8 +134,8 @@ __global__ __launch_bounds__(256) void suffix_attn_kernel(const SuffixArgs a) {
             // never predicate the loads (a branch per load serialises them): clamp to the last valid key,
             // its score is forced to -inf below so it contributes exactly 0
             const int kc = min(key, len - 1);
-            kreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb_ + (int64_t)kc * a.k_ts));
-            vreg[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb_ + (int64_t)kc * a.v_ts));
+            kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + ((unsigned)kc * krs + sub * 16)));
+            vreg[u] = __builtin_nontemporal_load((gu32x4_p)(vbu + ((unsigned)kc * vrs + sub * 16)));
         }
         float s[R][U];
 #pragma unroll
@@ -116,29 +149,36 @@ __global__ __launch_bounds__(256) void suffix_attn_kernel(const SuffixArgs a) {
                 s[r][u] = valid[u] ? d * sc : -INFINITY;
             }
         }
-        float vf[U][8];
-#pragma unroll
-        for (int u = 0; u < U; ++u) widen8<T>(vreg[u], vf[u]);
+        float mnew[R], alpha[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float cmax = s[r][0];
 #pragma unroll
             for (int u = 1; u < U; ++u) cmax = fmaxf(cmax, s[r][u]);
-            const float mn = fmaxf(m[r], cmax);
-            const float ms = (mn == -INFINITY) ? 0.f : mn;
-            const float alpha = fast_exp2(m[r] - ms);
+            mnew[r] = fmaxf(m[r], cmax);
+            const float ms = (mnew[r] == -INFINITY) ? 0.f : mnew[r];
+            alpha[r] = fast_exp2(m[r] - ms);
             float ps = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r][j] *= alpha;
-#pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float p = fast_exp2(s[r][u] - ms);
-                ps += p;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(p, vf[u][j], acc[r][j]);
+                s[r][u] = fast_exp2(s[r][u] - ms);  // p
+                ps += s[r][u];
             }
-            l[r] = l[r] * alpha + ps;
-            m[r] = mn;
+            l[r] = l[r] * alpha[r] + ps;
+            m[r] = mnew[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r][j] *= alpha[r];
+        }
+        // V is widened one key at a time, right where it is consumed (keeps the register footprint,
+        // hence the occupancy that hides HBM latency, independent of U)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float vf[8];
+            widen8<T>(vreg[u], vf);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(s[r][u], vf[j], acc[r][j]);
         }
     }
 
@@ -200,14 +240,24 @@ __global__ __launch_bounds__(256) void suffix_attn_kernel(const SuffixArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) num[j] = acc[r][j] * inv;
         } else {
-            float M = lse_s;
-            for (int i = 0; i < a.n_partials; ++i) M = fmaxf(M, a.partials[i].lse[ridx]);
+            const int i0 = pre0 ? 1 : 0;  // partial 0 already sits in registers
+            const float l0 = pl0[r / KPI];
+            float M = pre0 ? fmaxf(lse_s, l0) : lse_s;
+            for (int i = i0; i < a.n_partials; ++i) M = fmaxf(M, a.partials[i].lse[ridx]);
             const float Ms = (M == -INFINITY) ? 0.f : M;
             const float ws = __expf(lse_s - Ms);
             float den = ws;
 #pragma unroll
             for (int j = 0; j < 8; ++j) num[j] = acc[r][j] * (inv * ws);
-            for (int i = 0; i < a.n_partials; ++i) {
+            if (pre0) {
+                const float w = __expf(l0 - Ms);
+                den += w;
+                float pv[8];
+                widen8<T>(po0[r / KPI], pv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
+            }
+            for (int i = i0; i < a.n_partials; ++i) {
                 const float w = __expf(a.partials[i].lse[ridx] - Ms);
                 den += w;
                 float pv[8];
