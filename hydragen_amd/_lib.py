@@ -68,6 +68,20 @@ class DecodeParams(C.Structure):
     ]
 
 
+class RopeParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("q_out", C.c_void_p),
+        ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
+        ("position_ids", C.c_void_p), ("shared_len", C.c_void_p), ("seq_lens", C.c_void_p),
+        ("q_batch_stride", C.c_int64), ("k_batch_stride", C.c_int64), ("v_batch_stride", C.c_int64),
+        ("kc_batch_stride", C.c_int64), ("kc_tok_stride", C.c_int64), ("kc_head_stride", C.c_int64),
+        ("vc_batch_stride", C.c_int64), ("vc_tok_stride", C.c_int64), ("vc_head_stride", C.c_int64),
+        ("pos_stride", C.c_int64), ("cs_stride", C.c_int64),
+        ("dtype", C.c_int32), ("B", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32), ("D", C.c_int32),
+        ("cache_len", C.c_int32),
+    ]
+
+
 # every symbol include/hydragen_hip.h declares
 EXPORTS = {
     "hyd_version": (C.c_int, []),
@@ -80,6 +94,7 @@ EXPORTS = {
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hyd_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeParams)]),
     "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
+    "hyd_rope_append_decode": (C.c_int, [C.POINTER(RopeParams), C.c_void_p]),
     "hyd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

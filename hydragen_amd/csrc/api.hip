@@ -122,6 +122,19 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
 
 // Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
 // `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
+// Two implementations of the prefix pass exist while the faster one is being established on hardware:
+// "w8" (8 waves, 2 per SIMD, key-split) and "p4" (4 waves, 1 per SIMD, software-pipelined).
+// HYD_PREFIX_IMPL=w8|p4 overrides the default.
+int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
+    static const int impl = [] {
+        const char* e = getenv("HYD_PREFIX_IMPL");
+        if (e && !strcmp(e, "p4")) return 1;
+        if (e && !strcmp(e, "w8")) return 0;
+        return 0;
+    }();
+    return impl ? launch_prefix_p4(a, dtype, D, causal, grid, s) : launch_prefix(a, dtype, D, causal, grid, s);
+}
+
 int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s) {
     PrefixArgs a;
     fill_prefix_args(p, pl, &a);
@@ -131,7 +144,7 @@ int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hip
         a.lse = p->lse;
         a.out_f32 = 0;
         a.lse_layout = p->lse_layout;
-        int rc = launch_prefix(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
+        int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
         return rc ? fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc) : HYD_OK;
     }
     const size_t need = prefix_ws_bytes(p, pl);
@@ -148,7 +161,7 @@ int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hip
     a.lse_layout = HYD_LSE_BQH;
     a.out_split_stride = (int64_t)(o_bytes / sizeof(float));
     a.lse_split_stride = (int64_t)(l_bytes / sizeof(float));
-    int rc = launch_prefix(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
+    int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
     if (rc) return fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc);
     if (!merge) return HYD_OK;
     CombineArgs c;
@@ -362,6 +375,37 @@ int hyd_combine_lse(const void* const* outs, const float* const* lses, int32_t n
     c.scalar_only = aligned ? 0 : 1;  // unaligned views take the element-wise kernel
     int rc = launch_combine(c, static_cast<hipStream_t>(stream));
     return rc ? fail(HYD_ERR_LAUNCH, "combine kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
+int hyd_rope_append_decode(const hyd_rope_params* p, void* stream) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    int rc = check_common(p->dtype, p->B, 1, p->Hq, p->Hkv, p->D);
+    if (rc) return rc;
+    if ((rc = check_ptr_align(p->q, "q")) || (rc = check_ptr_align(p->k, "k")) || (rc = check_ptr_align(p->v, "v")) ||
+        (rc = check_ptr_align(p->q_out, "q_out")) || (rc = check_ptr_align(p->k_cache, "k_cache")) ||
+        (rc = check_ptr_align(p->v_cache, "v_cache")) || (rc = check_ptr_align(p->cos, "cos")) ||
+        (rc = check_ptr_align(p->sin, "sin")))
+        return rc;
+    if (!p->position_ids || !p->seq_lens) return fail(HYD_ERR_BAD_ARG, "position_ids / seq_lens is null");
+    if ((rc = check_stride8(p->q_batch_stride, "q_batch_stride")) || (rc = check_stride8(p->k_batch_stride, "k_batch_stride")) ||
+        (rc = check_stride8(p->v_batch_stride, "v_batch_stride")) || (rc = check_stride8(p->kc_batch_stride, "kc_batch_stride")) ||
+        (rc = check_stride8(p->kc_tok_stride, "kc_tok_stride")) || (rc = check_stride8(p->kc_head_stride, "kc_head_stride")) ||
+        (rc = check_stride8(p->vc_batch_stride, "vc_batch_stride")) || (rc = check_stride8(p->vc_tok_stride, "vc_tok_stride")) ||
+        (rc = check_stride8(p->vc_head_stride, "vc_head_stride")))
+        return rc;
+    if (p->cs_stride % 4 != 0) return fail(HYD_ERR_BAD_ARG, "cos/sin row stride must be a multiple of 4 floats");
+    if (p->cache_len <= 0) return fail(HYD_ERR_BAD_ARG, "cache_len %d", p->cache_len);
+    RopeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = p->q; a.k = p->k; a.v = p->v; a.q_out = p->q_out; a.k_cache = p->k_cache; a.v_cache = p->v_cache;
+    a.cos = p->cos; a.sin = p->sin; a.pos = p->position_ids; a.shared_len = p->shared_len; a.seq_lens = p->seq_lens;
+    a.q_bs = p->q_batch_stride; a.k_bs = p->k_batch_stride; a.v_bs = p->v_batch_stride;
+    a.kc_bs = p->kc_batch_stride; a.kc_ts = p->kc_tok_stride; a.kc_hs = p->kc_head_stride;
+    a.vc_bs = p->vc_batch_stride; a.vc_ts = p->vc_tok_stride; a.vc_hs = p->vc_head_stride;
+    a.pos_stride = p->pos_stride; a.cs_stride = p->cs_stride;
+    a.B = p->B; a.Hq = p->Hq; a.Hkv = p->Hkv; a.cache_len = p->cache_len;
+    rc = launch_rope_append(a, p->dtype, p->D, static_cast<hipStream_t>(stream));
+    return rc ? fail(HYD_ERR_LAUNCH, "rope_append kernel launch failed: hip error %d", rc) : HYD_OK;
 }
 
 size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {

@@ -62,8 +62,28 @@ struct CombineArgs {
     int32_t scalar_only;  // force the element-wise kernel (unaligned tensors)
 };
 
+struct RopeArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* q_out;
+    void* k_cache;
+    void* v_cache;
+    const float* cos;
+    const float* sin;
+    const int64_t* pos;
+    const int64_t* shared_len;  // may be null
+    int32_t* seq_lens;
+    int64_t q_bs, k_bs, v_bs;          // batch strides of q/k/v (elements); heads contiguous
+    int64_t kc_bs, kc_ts, kc_hs, vc_bs, vc_ts, vc_hs;
+    int64_t pos_stride, cs_stride;
+    int32_t B, Hq, Hkv, cache_len;
+};
+
 // launchers (defined next to the kernels); return hipError_t as int
 int launch_prefix(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
+int launch_prefix_p4(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
+int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 int launch_combine(const CombineArgs& a, hipStream_t s);
 

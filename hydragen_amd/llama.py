@@ -1,0 +1,726 @@
+"""
+Model shell around the hot path: the counterpart of /root/reference/hydragen/llama.py with the same
+class / method names and semantics (`HydragenLlamaForCausalLM.setup_caches / graph / append_shared /
+process_unique / generate / empty_shared_cache / truncate_shared_caches`), written from scratch so it
+does not depend on a particular `transformers` version (the reference pins 4.37.2, llama.py:1-10).
+
+What is native here: every attention call goes to the HIP kernels (hydragen_amd.attention / flash), and
+the per-token RoPE + unique-KV append + seq_lens computation of the decode step is ONE HIP kernel
+(`hyd_rope_append_decode`, replacing llama.py:236-262,317-330,485-501,565-569).  The dense layers
+(q/k/v/o projections, SwiGLU MLP, lm_head) are plain torch matmuls (hipBLASLt) -- plumbing, as in the
+reference.  Weights are random-initialised from a config (`from_config`); loading Hugging Face
+checkpoints is out of scope here (no network), but `load_state_dict` of a HF Llama state dict works
+because parameter names match (llama.py:1398-1422).
+
+Decode runs under a HIP graph exactly like the reference's CUDA-graph wrapper (llama.py:781-866).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Union
+
+import torch
+from torch import Tensor, nn
+
+from .attention import hydragen_attention
+from .flash import flash_attention, flash_attention_seqlen
+from .tp import all_reduce_sum
+
+
+@dataclass
+class LlamaConfig:
+    """The subset of transformers.LlamaConfig the reference reads (llama.py:423-462,635-653)."""
+
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    vocab_size: int = 32000
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_position_embeddings: int = 4096
+    attention_bias: bool = False
+    pad_token_id: Optional[int] = None
+
+    @staticmethod
+    def llama2_7b(**kw):
+        return LlamaConfig(**kw)
+
+    @staticmethod
+    def llama3_70b(**kw):
+        return LlamaConfig(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64,
+                           num_key_value_heads=8, vocab_size=128256, rope_theta=500000.0,
+                           max_position_embeddings=8192, **kw)
+
+
+def repeat_to_batch_size(tensors: list[Tensor], target_batch_size: int | None = None):
+    """llama.py:32-46."""
+    if target_batch_size is None:
+        target_batch_size = max(t.shape[0] for t in tensors)
+    out = []
+    for t in tensors:
+        assert target_batch_size % t.shape[0] == 0
+        out.append(t.repeat_interleave(target_batch_size // t.shape[0], dim=0))
+    return out
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        dt = x.dtype
+        x = x.float()
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * x.to(dt)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+        self.tp_reduce = False  # row-parallel down_proj needs the all-reduce of tp.py:83-87
+
+    def forward(self, x):
+        y = self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+        return all_reduce_sum(y) if self.tp_reduce else y
+
+
+class RotaryTable(nn.Module):
+    """cos/sin cache [max_pos, head_dim] in the rotate-half convention the reference uses through HF's
+    apply_rotary_pos_emb (llama.py:49-55,494-501)."""
+
+    def __init__(self, dim, max_position_embeddings, base, device=None):
+        super().__init__()
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32, device=device) / dim))
+        t = torch.arange(max_position_embeddings, dtype=torch.float32, device=device)
+        freqs = torch.outer(t, inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        self.register_buffer("cos_cached", emb.cos(), persistent=False)
+        self.register_buffer("sin_cached", emb.sin(), persistent=False)
+
+
+def rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2 :]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary_pos_emb(q, k, cos, sin, position_ids):
+    """q,k [b, s, h, d]; cos/sin [max_pos, d]; position_ids [b, s] absolute (llama.py:485-501)."""
+    cos = cos[position_ids].unsqueeze(2).to(q.dtype)
+    sin = sin[position_ids].unsqueeze(2).to(q.dtype)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+class SharedCache(nn.Module):
+    """llama.py:58-170: one shared level, sequences packed back to back in [maxB*maxP, Hkv, D]."""
+
+    def __init__(self, max_batch_size, max_seq_length, num_heads, head_dim, dtype, device):
+        super().__init__()
+        self.register_buffer("k_cache", torch.zeros((max_batch_size * max_seq_length, num_heads, head_dim), dtype=dtype, device=device), persistent=False)
+        self.register_buffer("v_cache", torch.zeros_like(self.k_cache), persistent=False)
+        self.register_buffer("seq_lens", torch.zeros((max_batch_size,), dtype=torch.int32, device=device), persistent=False)
+        self.register_buffer("cumsum_lengths", torch.zeros((max_batch_size + 1,), dtype=torch.int32, device=device), persistent=False)
+        self.max_batch_size = max_batch_size
+        self.max_sequence_length = max_seq_length
+        self.current_batch_size = 0
+        self.use_varlen = False
+        self.sliced_sequence_length = None
+
+    def get_current_batch_size(self):
+        return self.current_batch_size
+
+    def fill(self, key_states: Tensor, value_states: Tensor, seq_lens: Tensor):
+        bs = key_states.shape[0]
+        if bs > self.max_batch_size:
+            raise ValueError(f"Batch size {bs} exceeds max batch size {self.max_batch_size}")
+        if key_states.shape[1] > self.max_sequence_length:
+            raise ValueError(f"Sequence length {key_states.shape[1]} exceeds max sequence length {self.max_sequence_length}")
+        lens = [int(x) for x in seq_lens.tolist()]  # host sync, as llama.py:159-167
+        ks = torch.cat([key_states[i, : lens[i]] for i in range(bs)], dim=0)
+        vs = torch.cat([value_states[i, : lens[i]] for i in range(bs)], dim=0)
+        self.k_cache[: ks.shape[0]] = ks
+        self.v_cache[: vs.shape[0]] = vs
+        self.seq_lens[:bs] = seq_lens.to(torch.int32)
+        self.cumsum_lengths[0] = 0
+        self.cumsum_lengths[1 : bs + 1] = seq_lens.cumsum(0).to(torch.int32)
+        self.use_varlen = max(lens) != min(lens)
+        self.sliced_sequence_length = None if self.use_varlen else lens[0]
+        self.current_batch_size = bs
+
+    def get_used_cumsum_lengths(self):
+        return self.cumsum_lengths[: self.current_batch_size + 1]
+
+
+class PerLayerKVCache(nn.Module):
+    """llama.py:173-346."""
+
+    def __init__(self, max_unique_batch_size, max_unique_seq_length, max_shared_batch_sizes, max_shared_seq_lengths,
+                 n_kv_heads, head_dim, device, dtype):
+        super().__init__()
+        shape = (max_unique_batch_size, max_unique_seq_length, n_kv_heads, head_dim)
+        self.register_buffer("per_completion_k_cache", torch.zeros(shape, dtype=dtype, device=device))
+        self.register_buffer("per_completion_v_cache", torch.zeros(shape, dtype=dtype, device=device))
+        self.shared_caches = nn.ModuleList([
+            SharedCache(b, s, n_kv_heads, head_dim, dtype, device)
+            for b, s in zip(max_shared_batch_sizes, max_shared_seq_lengths)
+        ])
+        self.num_used_shared_caches = 0
+
+    def empty_shared_cache(self):
+        self.truncate_shared_caches(0)
+
+    def get_num_total_shared_caches(self):
+        return len(self.shared_caches)
+
+    def truncate_shared_caches(self, n: int):
+        assert n <= self.get_num_total_shared_caches(), f"{n} {self.get_num_total_shared_caches()}"
+        self.num_used_shared_caches = n
+
+    def update_per_completion_kvs(self, input_pos: Tensor, k_val: Tensor, v_val: Tensor):
+        """input_pos [bs, sl]; k_val/v_val [bs, sl, h, d] -> scatter into the caches (llama.py:236-262)."""
+        assert input_pos.shape[1] == k_val.shape[1], f"{input_pos.shape} {k_val.shape}"
+        bs, sl, h, d = k_val.shape
+        idx = input_pos[:, :, None, None].expand(bs, -1, h, d).to(torch.int64)
+        self.per_completion_k_cache[:bs].scatter_(1, idx, k_val)
+        self.per_completion_v_cache[:bs].scatter_(1, idx, v_val)
+        return self.per_completion_k_cache[:bs], self.per_completion_v_cache[:bs]
+
+    @torch.no_grad()
+    def copy_shared_to_unique(self, total_num_sequences: int):
+        """llama.py:264-298 (the no-sharing baseline materialises the prefix per sequence)."""
+        assert self.num_used_shared_caches == 1, "Cannot copy shared without exactly one active shared cache"
+        sc: SharedCache = self.shared_caches[0]
+        sb = sc.get_current_batch_size()
+        assert total_num_sequences % sb == 0
+        rep = total_num_sequences // sb
+        cu = sc.cumsum_lengths.tolist()
+        for i in range(sb):
+            n = cu[i + 1] - cu[i]
+            self.per_completion_k_cache[i * rep : (i + 1) * rep, :n] = sc.k_cache[cu[i] : cu[i + 1]].unsqueeze(0)
+            self.per_completion_v_cache[i * rep : (i + 1) * rep, :n] = sc.v_cache[cu[i] : cu[i + 1]].unsqueeze(0)
+
+    @torch.no_grad()
+    def repeat_per_completion_cache_for_num_samples(self, current_size: int, num_samples: int):
+        if num_samples == 1:
+            return
+        self.per_completion_k_cache[: current_size * num_samples] = self.per_completion_k_cache[:current_size].repeat_interleave(num_samples, 0)
+        self.per_completion_v_cache[: current_size * num_samples] = self.per_completion_v_cache[:current_size].repeat_interleave(num_samples, 0)
+
+    def get_used_shared_caches(self) -> list[SharedCache]:
+        return list(self.shared_caches)[: self.num_used_shared_caches]
+
+    def get_shared_len(self, final_batch_size: int):
+        """llama.py:317-330: per-sequence total shared length [B] (long)."""
+        if self.num_used_shared_caches == 0:
+            return torch.zeros((final_batch_size,), dtype=torch.long, device=self.per_completion_k_cache.device)
+        lens = [c.seq_lens[: c.current_batch_size] for c in self.get_used_shared_caches()]
+        return sum(repeat_to_batch_size(lens, final_batch_size)).long()
+
+    def has_shared(self):
+        return self.num_used_shared_caches > 0
+
+    def append_shared(self, key_states, value_states, seq_lens):
+        if self.num_used_shared_caches >= self.get_num_total_shared_caches():
+            raise ValueError(f"No more available shared caches: {self.num_used_shared_caches} {self.get_num_total_shared_caches()}")
+        self.shared_caches[self.num_used_shared_caches].fill(key_states, value_states, seq_lens)
+        self.num_used_shared_caches += 1
+
+
+class AttentionMode:
+    SHARED_PREFILL = "shared-prefill"
+    UNIQUE_PREFILL = "unique-prefill"
+    DECODE = "decode"
+
+
+def hydragen_attention_on_caches(q, k, v, shared_caches: list[SharedCache], seq_len: Optional[Tensor] = None):
+    """llama.py:355-414: adapt the caches to the operator's arguments (views only, no copies)."""
+    keys, values, cu_seqlens, max_seqlens, use_varlens = [], [], [], [], []
+    for sc in shared_caches:
+        if sc.use_varlen:
+            keys.append(sc.k_cache)
+            values.append(sc.v_cache)
+            cu_seqlens.append(sc.get_used_cumsum_lengths())
+            max_seqlens.append(sc.max_sequence_length)
+        else:
+            b, s = sc.get_current_batch_size(), sc.sliced_sequence_length
+            keys.append(sc.k_cache[: b * s].view(b, s, *sc.k_cache.shape[1:]))
+            values.append(sc.v_cache[: b * s].view(b, s, *sc.v_cache.shape[1:]))
+            cu_seqlens.append(None)
+            max_seqlens.append(None)
+        use_varlens.append(sc.use_varlen)
+    return hydragen_attention(q, k, v, shared_ks=keys, shared_vs=values, shared_cu_seq_lens=cu_seqlens,
+                              shared_max_seq_lens=max_seqlens, use_varlens=use_varlens, seq_lens=seq_len)
+
+
+class HydragenLlamaAttention(nn.Module):
+    """llama.py:417-595."""
+
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.disable_hydragen = False
+        self.disable_attention = False
+        if self.head_dim * self.num_heads != self.hidden_size:
+            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size} and `num_heads`: {self.num_heads}).")
+        b = config.attention_bias
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=b)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=b)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=b)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=b)
+        self.kv_cache: Optional[PerLayerKVCache] = None
+        self.mode: Optional[str] = None
+        self.rotary_emb: Optional[RotaryTable] = None
+        self.tp_reduce = False  # row-parallel o_proj needs the all-reduce of tp.py:108-112
+        self.use_fused_decode = True
+
+    def forward(self, hidden_states: Tensor, position_ids: Tensor):
+        bsz, q_len, _ = hidden_states.shape
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        cos, sin = self.rotary_emb.cos_cached, self.rotary_emb.sin_cached
+
+        fused = (self.mode == AttentionMode.DECODE and self.use_fused_decode and q_len == 1
+                 and not self.disable_attention)
+        if fused:
+            # one HIP kernel: RoPE(q, k) at absolute positions, append k/v at (position - shared length),
+            # seq_lens = that index + 1  (replaces llama.py:485-501,565-569 and the scatter_ of :236-262)
+            from .fused_decode import rope_append_decode
+
+            shared_len = None if self.disable_hydragen else self.kv_cache.get_shared_len(bsz)
+            q, seq_lens = rope_append_decode(q, k, v, cos, sin, position_ids, shared_len,
+                                             self.kv_cache.per_completion_k_cache, self.kv_cache.per_completion_v_cache)
+            key_states = self.kv_cache.per_completion_k_cache[:bsz]
+            value_states = self.kv_cache.per_completion_v_cache[:bsz]
+            if not self.kv_cache.has_shared() or self.disable_hydragen:
+                attn_output, _ = flash_attention_seqlen(q, key_states, value_states, seq_len=seq_lens)
+            else:
+                attn_output = hydragen_attention_on_caches(q, key_states, value_states,
+                                                           self.kv_cache.get_used_shared_caches(), seq_len=seq_lens)
+            out = self.o_proj(attn_output.reshape(bsz, q_len, -1))
+            return all_reduce_sum(out) if self.tp_reduce else out
+
+        if self.disable_hydragen:
+            unique_position_ids = position_ids
+        else:
+            unique_position_ids = position_ids - self.kv_cache.get_shared_len(position_ids.shape[0]).unsqueeze(-1)
+        q, k = apply_rotary_pos_emb(q, k, cos, sin, position_ids)
+
+        if self.disable_attention:
+            attn_output = q
+        elif self.mode == AttentionMode.SHARED_PREFILL:
+            if not self.kv_cache.has_shared():
+                attn_output, _ = flash_attention(q, k, v, causal=True)
+            else:
+                attn_output = hydragen_attention_on_caches(q, k, v, self.kv_cache.get_used_shared_caches())
+            self.kv_cache.append_shared(k, v, unique_position_ids.max(1).values + 1)
+        elif self.mode == AttentionMode.UNIQUE_PREFILL:
+            if self.disable_hydragen:
+                ks, vs = self.kv_cache.update_per_completion_kvs(unique_position_ids, k, v)
+                n = int(unique_position_ids.max().item()) + 1
+                attn_output, _ = flash_attention(q, ks[:, :n], vs[:, :n], causal=True)
+            else:
+                if not self.kv_cache.has_shared():
+                    attn_output, _ = flash_attention(q, k, v, causal=True)
+                else:
+                    attn_output = hydragen_attention_on_caches(q, k, v, self.kv_cache.get_used_shared_caches())
+                self.kv_cache.update_per_completion_kvs(unique_position_ids, k, v)
+        elif self.mode == AttentionMode.DECODE:
+            ks, vs = self.kv_cache.update_per_completion_kvs(unique_position_ids, k, v)
+            seq_lens = unique_position_ids.squeeze(-1) + 1
+            if not self.kv_cache.has_shared() or self.disable_hydragen:
+                attn_output, _ = flash_attention_seqlen(q, ks, vs, seq_len=seq_lens)
+            else:
+                attn_output = hydragen_attention_on_caches(q, ks, vs, self.kv_cache.get_used_shared_caches(), seq_len=seq_lens)
+        else:
+            raise ValueError(f"Unknown mode {self.mode}")
+
+        out = self.o_proj(attn_output.reshape(bsz, q_len, -1))
+        return all_reduce_sum(out) if self.tp_reduce else out
+
+
+class HydragenLlamaDecoderLayer(nn.Module):
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.self_attn = HydragenLlamaAttention(config)
+        self.mlp = LlamaMLP(config)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, position_ids):
+        hidden_states = hidden_states + self.self_attn(self.input_layernorm(hidden_states), position_ids)
+        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+
+
+class HydragenLlamaModel(nn.Module):
+    """llama.py:636-765."""
+
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, config.pad_token_id)
+        self.layers = nn.ModuleList([HydragenLlamaDecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.rotary_emb = RotaryTable(config.hidden_size // config.num_attention_heads,
+                                      config.max_position_embeddings, config.rope_theta)
+        for layer in self.layers:
+            layer.self_attn.rotary_emb = self.rotary_emb
+
+    def set_disable_hydragen(self, disable=True):
+        for layer in self.layers:
+            layer.self_attn.disable_hydragen = disable
+
+    def get_disable_hydragen(self):
+        return self.layers[0].self_attn.disable_hydragen
+
+    def set_disable_attention(self, disable=True):
+        for layer in self.layers:
+            layer.self_attn.disable_attention = disable
+
+    def get_disable_attention(self):
+        return self.layers[0].self_attn.disable_attention
+
+    def copy_shared_cache_to_unique(self, total_num_sequences):
+        for layer in self.layers:
+            layer.self_attn.kv_cache.copy_shared_to_unique(total_num_sequences)
+
+    def _used(self):
+        return self.layers[0].self_attn.kv_cache.get_used_shared_caches()
+
+    def get_shared_batch_sizes(self):
+        return [c.get_current_batch_size() for c in self._used()]
+
+    def get_shared_varlens(self):
+        return [c.use_varlen for c in self._used()]
+
+    def get_shared_slice_seq_lens(self):
+        return [c.sliced_sequence_length for c in self._used()]
+
+    def forward(self, input_ids, position_ids):
+        h = self.embed_tokens(input_ids)
+        for layer in self.layers:
+            h = layer(h, position_ids=position_ids)
+        return self.norm(h)
+
+
+@dataclass
+class CaptureData:
+    graph: "torch.cuda.CUDAGraph"
+    static_input_ids: Tensor
+    static_position_ids: Tensor
+    static_hidden: Tensor
+    key: tuple
+
+
+class GraphedHydragenLlamaModel(nn.Module):
+    """HIP-graph replay of the decode forward; re-captures on the same invalidation keys as
+    llama.py:791-823 (shapes, shared batch sizes, varlen flags, sliced lengths, disable flags)."""
+
+    def __init__(self, model: HydragenLlamaModel):
+        super().__init__()
+        self.model = model
+        self.capture_data: Optional[CaptureData] = None
+
+    def invalidate(self):
+        self.capture_data = None
+
+    def _key(self, input_ids, position_ids):
+        m = self.model
+        return (tuple(input_ids.shape), tuple(position_ids.shape), tuple(m.get_shared_batch_sizes()),
+                m.get_disable_hydragen(), m.get_disable_attention(), tuple(m.get_shared_varlens()),
+                tuple(m.get_shared_slice_seq_lens()))
+
+    def forward(self, input_ids, position_ids):
+        key = self._key(input_ids, position_ids)
+        if self.capture_data is not None and self.capture_data.key != key:
+            self.invalidate()
+        if self.capture_data is None:
+            self.capture(input_ids, position_ids, key)
+        self.capture_data.static_input_ids.copy_(input_ids)
+        self.capture_data.static_position_ids.copy_(position_ids)
+        self.capture_data.graph.replay()
+        return self.capture_data.static_hidden
+
+    def capture(self, input_ids, position_ids, key):
+        static_input_ids = input_ids.clone()
+        static_position_ids = position_ids.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):  # warm-up on a side stream (llama.py:838-845)
+                self.model(input_ids=static_input_ids, position_ids=static_position_ids)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_hidden = self.model(input_ids=static_input_ids, position_ids=static_position_ids)
+        self.capture_data = CaptureData(g, static_input_ids, static_position_ids, static_hidden, key)
+
+
+class SharedCacheOp:
+    WIPE = "wipe"
+    EXTEND = "extend"
+    PRESERVE = "preserve"
+
+
+class HydragenLlamaForCausalLM(nn.Module):
+    """llama.py:875-1422."""
+
+    def __init__(self, config: LlamaConfig):
+        super().__init__()
+        self.config = config
+        self.model = HydragenLlamaModel(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.kv_cache_allocated = False
+        self.graphed_model: Optional[GraphedHydragenLlamaModel] = None
+        self.mode: Optional[str] = None
+
+    # ---- construction -----------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config: LlamaConfig, dtype=torch.bfloat16, device="cuda", seed: int = 0, std: float = 0.02):
+        """Random-weight model of the given architecture (synthetic benchmarks / tests)."""
+        with torch.device(device):
+            model = cls(config)
+        model.to(dtype=dtype)
+        model.model.rotary_emb.float()  # cos/sin tables stay fp32 (cast per use, like HF's rotary embedding)
+        g = torch.Generator(device=device).manual_seed(seed)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if p.ndim >= 2:
+                    p.normal_(0.0, std, generator=g)
+        model.device, model.dtype = torch.device(device), dtype
+        return model
+
+    @classmethod
+    def from_pretrained(cls, model_name_or_path: str, **kwargs):
+        """llama.py:1398-1422.  Needs `transformers` weights on disk; not exercised offline."""
+        from transformers import LlamaForCausalLM  # pragma: no cover
+
+        hf = LlamaForCausalLM.from_pretrained(model_name_or_path, **kwargs)  # pragma: no cover
+        if hf.dtype not in (torch.float16, torch.bfloat16):  # pragma: no cover
+            raise ValueError(f"Model must be in float16 or bfloat16, not {hf.dtype}")
+        c = hf.config  # pragma: no cover
+        rp = getattr(c, "rope_parameters", None) or {}
+        cfg = LlamaConfig(c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
+                          c.num_key_value_heads, c.vocab_size, c.rms_norm_eps,
+                          getattr(c, "rope_theta", rp.get("rope_theta", 10000.0)), c.max_position_embeddings,
+                          getattr(c, "attention_bias", False), c.pad_token_id)  # pragma: no cover
+        model = cls(cfg)  # pragma: no cover
+        model.load_state_dict(hf.state_dict(), strict=False)  # pragma: no cover
+        model.to(device=hf.device, dtype=hf.dtype)  # pragma: no cover
+        model.model.rotary_emb.float()  # pragma: no cover
+        model.device, model.dtype = hf.device, hf.dtype  # pragma: no cover
+        return model  # pragma: no cover
+
+    # ---- cache / graph management -------------------------------------------------------------------
+    def set_mode(self, mode):
+        self.mode = mode
+        for layer in self.model.layers:
+            layer.self_attn.mode = mode
+
+    def graph(self, do_graph: bool = True):
+        """Controls whether decoding replays a HIP graph (llama.py:898-907)."""
+        if do_graph:
+            if self.graphed_model is None:
+                self.graphed_model = GraphedHydragenLlamaModel(self.model)
+        else:
+            self.graphed_model = None
+
+    def maybe_invalidate(self):
+        if self.graphed_model is not None:
+            self.graphed_model.invalidate()
+
+    def get_num_heads(self):
+        return self.config.num_attention_heads
+
+    def setup_caches(self, max_unique_batch_size: int, max_unique_seq_length: int,
+                     max_shared_batch_sizes: list[int], max_shared_seq_lengths: list[int]):
+        """Allocate the unique KV cache and the shared cache levels at every layer (llama.py:921-955)."""
+        self.maybe_invalidate()
+        max_unique_seq_length = (max_unique_seq_length + 15) // 16 * 16
+        for layer in self.model.layers:
+            layer.self_attn.kv_cache = PerLayerKVCache(
+                max_unique_batch_size=max_unique_batch_size, max_unique_seq_length=max_unique_seq_length,
+                max_shared_batch_sizes=max_shared_batch_sizes, max_shared_seq_lengths=max_shared_seq_lengths,
+                n_kv_heads=self.config.num_key_value_heads,
+                head_dim=self.config.hidden_size // self.get_num_heads(),
+                device=self.lm_head.weight.device, dtype=self.lm_head.weight.dtype)
+        self.kv_cache_allocated = True
+
+    def empty_shared_cache(self):
+        for layer in self.model.layers:
+            layer.self_attn.kv_cache.empty_shared_cache()
+
+    def truncate_shared_caches(self, new_num_shared_caches: int):
+        for layer in self.model.layers:
+            layer.self_attn.kv_cache.truncate_shared_caches(new_num_shared_caches)
+
+    def get_shared_cache_len(self, batch_size):
+        return self.model.layers[0].self_attn.kv_cache.get_shared_len(batch_size)
+
+    def get_num_used_shared_caches(self):
+        return self.model.layers[0].self_attn.kv_cache.num_used_shared_caches
+
+    def repeat_per_completion_cache_for_num_samples(self, current_size, num_samples):
+        for layer in self.model.layers:
+            layer.self_attn.kv_cache.repeat_per_completion_cache_for_num_samples(current_size, num_samples)
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, input_ids, position_ids, seq_lens=None, use_graph=False, full_logits=False):
+        model = self.graphed_model if use_graph else self.model
+        assert model is not None
+        hidden = model(input_ids=input_ids, position_ids=position_ids)
+        if full_logits:
+            to_lm_head = hidden
+        elif seq_lens is not None:
+            to_lm_head = hidden[torch.arange(hidden.shape[0], device=hidden.device), seq_lens - 1].unsqueeze(1)
+        else:
+            to_lm_head = hidden[:, -1:]
+        return self.lm_head(to_lm_head).float()
+
+    def apply_top_p(self, logits, top_p, min_tokens_to_keep=1, filter_value=-float("Inf")):
+        sorted_logits, sorted_indices = torch.sort(logits, descending=False)
+        cumulative_probs = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cumulative_probs <= (1 - top_p)
+        remove[..., -min_tokens_to_keep:] = 0
+        return logits.masked_fill(remove.scatter(1, sorted_indices, remove), filter_value)
+
+    def sample_from_logits(self, logits, temperature, num_samples=1, top_p=None):
+        if top_p is not None:
+            logits = self.apply_top_p(logits, top_p)
+        if temperature == 0:
+            assert logits.ndim == 2
+            return logits.argmax(dim=-1, keepdim=True).repeat_interleave(num_samples, dim=-1)
+        probs = nn.functional.softmax(logits / temperature, dim=-1)
+        return torch.multinomial(probs, num_samples=num_samples, replacement=True)
+
+    def _positions(self, input_ids):
+        shared_lens = self.get_shared_cache_len(input_ids.shape[0])
+        n = input_ids.shape[1]
+        return shared_lens[:, None] + torch.arange(n, device=input_ids.device, dtype=torch.long)[None, :]
+
+    @torch.no_grad()
+    def append_shared(self, input_ids, seq_lens=None, full_logits=False):
+        """Add a new level of shared cache (llama.py:1073-1116).  Padding on the right."""
+        self.set_mode(AttentionMode.SHARED_PREFILL)
+        position_ids = self._positions(input_ids)
+        if seq_lens is not None:
+            last = position_ids.gather(1, (seq_lens.long() - 1)[:, None])
+            ar = torch.arange(input_ids.shape[1], device=input_ids.device)[None, :]
+            position_ids = torch.where(ar >= seq_lens.long()[:, None], last, position_ids)
+        return self(input_ids=input_ids, position_ids=position_ids, seq_lens=seq_lens, full_logits=full_logits)
+
+    @torch.no_grad()
+    def process_unique(self, input_ids, seq_lens=None):
+        """Prefill of per-sequence (unique) prompts (llama.py:1118-1145)."""
+        self.set_mode(AttentionMode.UNIQUE_PREFILL)
+        return self(input_ids=input_ids, position_ids=self._positions(input_ids), seq_lens=seq_lens)
+
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[Union[Tensor, list[Tensor]]] = None,
+                 seq_lens: Optional[Union[Tensor, list[Tensor]]] = None, starting_logits: Optional[Tensor] = None,
+                 num_return_sequences: int = 1, max_new_tokens: int = 5, temperature: float = 1.0,
+                 top_p: Optional[float] = None, eos_token_id: Optional[int] = None, return_logits: bool = False,
+                 shared_cache_op: str = SharedCacheOp.PRESERVE, disable_hydragen: bool = False,
+                 disable_attention: bool = False, disable_hierarchy: bool = False,
+                 token_overrides: Optional[Tensor] = None):
+        """Same contract as llama.py:1156-1396 (hierarchical prompts as a list of id tensors, last level
+        optionally multiplied by num_return_sequences; shared_cache_op wipe/preserve/extend; the
+        disable_* switches are the paper's baselines; token_overrides forces tokens for testing)."""
+        assert self.kv_cache_allocated
+        assert (input_ids is None) or (starting_logits is None)
+        assert not (input_ids is None and starting_logits is None)
+        if input_ids is None:
+            input_ids = []
+        if temperature < 0:
+            raise ValueError(f"temperature must be non-negative, {temperature} is invalid")
+        if disable_attention:
+            self.model.set_disable_attention(True)
+        if shared_cache_op == SharedCacheOp.WIPE:
+            self.empty_shared_cache()
+        og = self.get_num_used_shared_caches()
+        if isinstance(input_ids, Tensor):
+            input_ids = [input_ids]
+        num_new_levels = len(input_ids) + (1 if num_return_sequences > 1 else 0)
+        total_levels = og + num_new_levels
+        if disable_hydragen:
+            assert total_levels == 2
+            if num_new_levels == 2:
+                assert input_ids[0].shape[0] == 1
+        if disable_hierarchy:
+            assert total_levels == 3 and num_return_sequences > 1
+        if isinstance(seq_lens, Tensor):
+            seq_lens = [seq_lens]
+        elif seq_lens is None:
+            seq_lens = [torch.full((x.shape[0],), x.shape[1], device=x.device, dtype=torch.long) for x in input_ids]
+        if len(input_ids) > 0:
+            total_batch_size = input_ids[-1].shape[0] * num_return_sequences
+        else:
+            total_batch_size = starting_logits.shape[0] * num_return_sequences
+
+        if num_return_sequences > 1 and not (disable_hierarchy or disable_hydragen):
+            shared_ids, shared_seq_lens, suffix_ids, suffix_seq_lens = input_ids, seq_lens, None, None
+        elif len(input_ids) > 0:
+            shared_ids, shared_seq_lens = input_ids[:-1], seq_lens[:-1]
+            suffix_ids, suffix_seq_lens = input_ids[-1], seq_lens[-1]
+        else:
+            shared_ids, shared_seq_lens, suffix_ids, suffix_seq_lens = [], [], None, None
+
+        if starting_logits is not None:
+            starting_logits = starting_logits.unsqueeze(1)
+        for sid, slen in zip(shared_ids, shared_seq_lens):
+            starting_logits = self.append_shared(sid, slen)
+        if disable_hydragen:
+            self.model.set_disable_hydragen(True)
+            if self.get_num_used_shared_caches() > 0:
+                self.model.copy_shared_cache_to_unique(total_batch_size)
+        if suffix_ids is not None:
+            starting_logits = self.process_unique(suffix_ids, suffix_seq_lens)
+            self.repeat_per_completion_cache_for_num_samples(suffix_ids.shape[0], num_return_sequences)
+
+        prefill_logits = starting_logits[:, -1]
+        first = self.sample_from_logits(prefill_logits, temperature=temperature, num_samples=num_return_sequences, top_p=top_p)
+        first_token_ids = first.reshape(-1, 1)
+        logits_to_return = [prefill_logits.repeat_interleave(num_return_sequences, 0)] if return_logits else None
+
+        starting_position_ids = self.get_shared_cache_len(first_token_ids.shape[0])[:, None]
+        if suffix_seq_lens is not None:
+            starting_position_ids = starting_position_ids + suffix_seq_lens.long().repeat_interleave(num_return_sequences, 0)[:, None]
+        finished = (first_token_ids == eos_token_id) if eos_token_id is not None else None
+        decoded = [first_token_ids]
+        current = first_token_ids if token_overrides is None else token_overrides[:, 0:1]
+
+        self.set_mode(AttentionMode.DECODE)
+        for i in range(max_new_tokens - 1):
+            position_ids = starting_position_ids + i
+            logits = self(input_ids=current, position_ids=position_ids, use_graph=self.graphed_model is not None)
+            if return_logits:
+                logits_to_return.append(logits[:, -1])
+            current = self.sample_from_logits(logits[:, -1], temperature=temperature, top_p=top_p)
+            if finished is not None:
+                finished = torch.logical_or(finished, current == eos_token_id)
+                if torch.all(finished):
+                    break
+            decoded.append(current)
+            if token_overrides is not None:
+                current = token_overrides[:, i + 1 : i + 2]
+        out = torch.cat(decoded, dim=-1)
+
+        if shared_cache_op == SharedCacheOp.PRESERVE:
+            self.truncate_shared_caches(og)
+        if disable_hydragen:
+            self.model.set_disable_hydragen(False)
+        if disable_attention:
+            self.model.set_disable_attention(False)
+        return (out, logits_to_return) if return_logits else out

@@ -164,6 +164,34 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
 size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32_t D, int32_t n_levels,
                            const int32_t* level_sb, const int32_t* level_kv_len);
 
+/* ------------------------------------------------------------------------------------------
+ * Decode-step preamble of the attention block: RoPE of this step's q and k at
+ * absolute positions (llama.py:485-501), append of k/v into the unique caches at index
+ * position - shared_len (llama.py:236-262, 487-492) and seq_lens = index + 1 (llama.py:569),
+ * in one kernel.  q/k/v are [B, 1, H, D] with heads contiguous; cos/sin are fp32 [max_pos, D]
+ * tables in the rotate-half convention (first D/2 columns are read).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hyd_rope_params {
+    const void* q;               /* [B, 1, Hq, D], batch stride q_batch_stride                   */
+    const void* k;               /* [B, 1, Hkv, D]                                               */
+    const void* v;               /* [B, 1, Hkv, D]                                               */
+    void* q_out;                 /* [B, 1, Hq, D] contiguous: rotated queries                    */
+    void* k_cache;               /* [maxB, cache_len, Hkv, D] with the strides below            */
+    void* v_cache;
+    const float* cos;            /* [max_pos, D] fp32, row stride cs_stride                      */
+    const float* sin;
+    const int64_t* position_ids; /* [B] absolute positions, element stride pos_stride            */
+    const int64_t* shared_len;   /* [B] or NULL (= 0)                                            */
+    int32_t* seq_lens;           /* out [B]                                                      */
+    int64_t q_batch_stride, k_batch_stride, v_batch_stride;
+    int64_t kc_batch_stride, kc_tok_stride, kc_head_stride;
+    int64_t vc_batch_stride, vc_tok_stride, vc_head_stride;
+    int64_t pos_stride, cs_stride;
+    int32_t dtype, B, Hq, Hkv, D, cache_len;
+} hyd_rope_params;
+
+int hyd_rope_append_decode(const hyd_rope_params* p, void* stream);
+
 int hyd_version(void);
 const char* hyd_last_error_string(void);
 

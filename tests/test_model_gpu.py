@@ -1,0 +1,170 @@
+"""-m gpu: the model shell (hydragen_amd/llama.py) around the HIP attention path, with random weights.
+Mirrors the reference's integration tests (tests/test_e2e.py): per-step decode logits against a plain
+causal transformer evaluated on the concatenated prompt (there: HF transformers; here: a torch fp32
+re-evaluation with the same weights), with token_overrides forcing identical tokens
+(tests/test_e2e.py:104-119, bounds :29-30), plus the A/B invariants hydragen vs no-sharing
+(:122-210) and hierarchy vs flattened (:213-298), and HIP-graph on/off."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rdiff(a, b, eps=1e-8):
+    return 2 * (a - b).abs() / (a.abs() + b.abs() + eps)
+
+
+def make_model(dtype, head_dim=64, kv_heads=2, layers=2, seed=0):
+    from hydragen_amd.llama import HydragenLlamaForCausalLM, LlamaConfig
+
+    cfg = LlamaConfig(hidden_size=4 * head_dim, intermediate_size=512, num_hidden_layers=layers,
+                      num_attention_heads=4, num_key_value_heads=kv_heads, vocab_size=512,
+                      max_position_embeddings=1024, rms_norm_eps=1e-5)
+    return HydragenLlamaForCausalLM.from_config(cfg, dtype=dtype, device=DEV, seed=seed, std=0.05)
+
+
+@torch.no_grad()
+def ref_logits(model, ids):
+    """fp32 causal transformer over full sequences ids [b, n] with the model's weights."""
+    from hydragen_amd.llama import rotate_half
+
+    cfg = model.config
+    H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    D = cfg.hidden_size // H
+    f = lambda t: t.float()
+    b, n = ids.shape
+    h = f(model.model.embed_tokens.weight)[ids]
+    pos = torch.arange(n, device=ids.device)
+    cos = model.model.rotary_emb.cos_cached[pos][None, :, None, :]
+    sin = model.model.rotary_emb.sin_cached[pos][None, :, None, :]
+
+    def norm(x, w, eps):
+        return f(w) * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+    for layer in model.model.layers:
+        a = layer.self_attn
+        x = norm(h, layer.input_layernorm.weight, cfg.rms_norm_eps)
+        q = (x @ f(a.q_proj.weight).T).view(b, n, H, D)
+        k = (x @ f(a.k_proj.weight).T).view(b, n, Hkv, D)
+        v = (x @ f(a.v_proj.weight).T).view(b, n, Hkv, D)
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        k = k.repeat_interleave(H // Hkv, 2)
+        v = v.repeat_interleave(H // Hkv, 2)
+        s = torch.einsum("bqhd,bkhd->bhqk", q, k) * D ** -0.5
+        s = s.masked_fill(torch.triu(torch.ones(n, n, device=ids.device, dtype=torch.bool), 1), float("-inf"))
+        o = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v).reshape(b, n, H * D)
+        h = h + o @ f(a.o_proj.weight).T
+        x = norm(h, layer.post_attention_layernorm.weight, cfg.rms_norm_eps)
+        m = layer.mlp
+        h = h + (torch.nn.functional.silu(x @ f(m.gate_proj.weight).T) * (x @ f(m.up_proj.weight).T)) @ f(m.down_proj.weight).T
+    h = norm(h, model.model.norm.weight, cfg.rms_norm_eps)
+    return h @ f(model.lm_head.weight).T
+
+
+def test_rope_append_kernel_vs_torch():
+    from hydragen_amd.fused_decode import rope_append_decode
+    from hydragen_amd.llama import RotaryTable, apply_rotary_pos_emb
+
+    for dtype, D, Hq, Hkv in ((torch.bfloat16, 128, 8, 2), (torch.float16, 64, 4, 4)):
+        B, maxS = 37, 48
+        g = torch.Generator(device=DEV).manual_seed(1)
+        qkv = torch.randn(B, 1, (Hq + 2 * Hkv) * D, device=DEV, dtype=dtype, generator=g)
+        q = qkv[..., : Hq * D].view(B, 1, Hq, D)                    # views of one projection output:
+        k = qkv[..., Hq * D : (Hq + Hkv) * D].view(B, 1, Hkv, D)    # non-trivial batch strides
+        v = qkv[..., (Hq + Hkv) * D :].view(B, 1, Hkv, D)
+        rot = RotaryTable(D, 512, 10000.0, device=DEV)
+        shared = torch.randint(0, 100, (B,), device=DEV, generator=g)
+        idx = torch.randint(0, maxS, (B,), device=DEV, generator=g)
+        pos = (shared + idx)[:, None]
+        kc = torch.zeros(B + 3, maxS, Hkv, D, device=DEV, dtype=dtype)
+        vc = torch.zeros_like(kc)
+        qo, sl = rope_append_decode(q, k, v, rot.cos_cached, rot.sin_cached, pos, shared, kc, vc)
+        qr, kr = apply_rotary_pos_emb(q.float(), k.float(), rot.cos_cached, rot.sin_cached, pos)
+        assert torch.equal(sl.long(), idx + 1)
+        tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+        assert (qo.float() - qr).abs().max() < tol
+        bi = torch.arange(B, device=DEV)
+        assert (kc[bi, idx].float() - kr[:, 0]).abs().max() < tol
+        assert torch.equal(vc[bi, idx], v[:, 0])
+        mask = torch.ones_like(kc, dtype=torch.bool)
+        mask[bi, idx] = False
+        assert kc[mask].abs().max() == 0 and vc[mask].abs().max() == 0   # nothing else was touched
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("spec", ["prefix+completions", "three-level", "padded-shared", "prefix+suffix"])
+def test_decode_logits_vs_fp32_transformer(dtype, graph, spec):
+    model = make_model(dtype, head_dim=64 if dtype == torch.float16 else 128)
+    model.graph(graph)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rnd = lambda *s: torch.randint(1, 512, s, device=DEV, generator=g)
+    new = 6
+    if spec == "prefix+completions":
+        ids, lens, nret = [rnd(1, 40)], None, 4
+    elif spec == "three-level":
+        ids, lens, nret = [rnd(1, 24), rnd(2, 9), rnd(4, 5)], None, 2
+    elif spec == "padded-shared":
+        ids, nret = [rnd(1, 30), rnd(2, 12)], 3
+        lens = [torch.tensor([30], device=DEV), torch.tensor([12, 7], device=DEV)]
+    else:
+        ids, lens, nret = [rnd(1, 33), rnd(4, 10)], None, 1
+    B = ids[-1].shape[0] * nret
+    model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=64,
+                       max_shared_batch_sizes=[x.shape[0] for x in ids], max_shared_seq_lengths=[x.shape[1] for x in ids])
+    overrides = rnd(B, new)
+    out, logits = model.generate(input_ids=ids, seq_lens=lens, num_return_sequences=nret, max_new_tokens=new,
+                                 temperature=0.0, return_logits=True, token_overrides=overrides)
+    assert out.shape == (B, new) and len(logits) == new
+    # reference: every completion's full token sequence through a plain causal transformer
+    for j in range(B):
+        parts = []
+        for li, x in enumerate(ids):
+            row = j // (B // x.shape[0])
+            n = x.shape[1] if lens is None else int(lens[li][row])
+            parts.append(x[row, :n])
+        parts.append(overrides[j, : new - 1])
+        full = torch.cat(parts)[None]
+        ref = ref_logits(model, full)[0]
+        nprompt = full.shape[1] - (new - 1)
+        got = torch.stack([l[j] for l in logits])                     # logits after prompt, tok1, ...
+        want = ref[nprompt - 1 :]
+        # fp16: the reference's bounds (tests/test_e2e.py:29-30,117-119).  bf16 (3 fewer mantissa bits, small
+        # random-weight logits): same absolute bound, mean relative bound scaled accordingly.
+        assert (got - want).abs().max() < 0.75, spec
+        assert rdiff(got, want).mean() < (0.05 if dtype == torch.float16 else 0.15), spec
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_hydragen_vs_nosharing_and_flat_hierarchy(dtype):
+    # fp16: the reference's bound (tests/test_e2e.py:210,298); bf16: scaled for its 3 fewer mantissa bits
+    bound = 0.02 if dtype == torch.float16 else 0.08
+    model = make_model(dtype, head_dim=128, kv_heads=4)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rnd = lambda *s: torch.randint(1, 512, s, device=DEV, generator=g)
+    prefix, new, nret = rnd(1, 50), 8, 6
+    overrides = rnd(nret, new)
+    model.setup_caches(max_unique_batch_size=nret, max_unique_seq_length=64 + 16, max_shared_batch_sizes=[1],
+                       max_shared_seq_lengths=[50])
+    kw = dict(input_ids=prefix, num_return_sequences=nret, max_new_tokens=new, temperature=0.0, return_logits=True,
+              token_overrides=overrides)
+    _, a = model.generate(**kw)
+    _, b = model.generate(disable_hydragen=True, **kw)                 # tests/test_e2e.py:122-210
+    assert rdiff(torch.stack(a), torch.stack(b)).mean() < bound
+    # hierarchy vs flattened: prefix + 2 second-level prompts + completions   (tests/test_e2e.py:213-298)
+    mid = rnd(2, 11)
+    overrides = rnd(2 * nret, new)
+    model.setup_caches(max_unique_batch_size=2 * nret, max_unique_seq_length=64, max_shared_batch_sizes=[1, 2],
+                       max_shared_seq_lengths=[50, 11])
+    kw = dict(input_ids=[prefix, mid], num_return_sequences=nret, max_new_tokens=new, temperature=0.0,
+              return_logits=True, token_overrides=overrides)
+    _, a = model.generate(**kw)
+    _, b = model.generate(disable_hierarchy=True, **kw)
+    assert rdiff(torch.stack(a), torch.stack(b)).mean() < bound
+    # fused RoPE/append kernel vs the torch scatter path
+    for layer in model.model.layers:
+        layer.self_attn.use_fused_decode = False
+    _, c = model.generate(**kw)
+    assert rdiff(torch.stack(a), torch.stack(c)).mean() < bound
