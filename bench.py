@@ -65,48 +65,38 @@ def parse():
 
 
 class Ops:
-    """The two kernels of one decode step, launched separately so HIP events can bracket each
-    (same kernels, same order and same arguments as hyd_decode_attn_fused issues them)."""
+    """One decode step = ONE call of the product's fused entry point (`hyd_decode_attn_fused`, what
+    hydragen_amd.attention.hydragen_attention issues), through its measurement twin
+    `hyd_decode_attn_fused_timed`, which records a HIP event between the prefix pass and the suffix pass
+    so that each kernel can be timed inside the timed region."""
 
     def __init__(self, q, k, v, sk, sv):
         from hydragen_amd import _lib
-        from hydragen_amd._lib import HYD_LSE_BQH, PrefixParams, SuffixParams
-        from hydragen_amd.flash import _dtype_code, fill_suffix_params
+        from hydragen_amd._lib import DecodeParams
+        from hydragen_amd.attention import _fill_level
+        from hydragen_amd.flash import fill_suffix_params
 
         self.lib = _lib.load()
         self._lib = _lib
-        B, nq, Hq, D = q.shape
-        self.q, self.k, self.v, self.sk, self.sv = q, k, v, sk, sv
+        B = q.shape[0]
         self.out = torch.empty_like(q)
-        self.pout = torch.empty_like(q)
-        self.plse = torch.empty(B, nq, Hq, dtype=torch.float32, device=q.device)
-        p = PrefixParams()
-        p.q, p.k, p.v, p.out, p.lse = q.data_ptr(), sk.data_ptr(), sv.data_ptr(), self.pout.data_ptr(), self.plse.data_ptr()
-        p.k_group_stride, p.k_tok_stride, p.k_head_stride = sk.stride(0), sk.stride(1), sk.stride(2)
-        p.v_group_stride, p.v_tok_stride, p.v_head_stride = sv.stride(0), sv.stride(1), sv.stride(2)
-        p.dtype = _dtype_code(q)
-        p.B, p.nq, p.Hq, p.Hkv, p.D = B, nq, Hq, sk.shape[2], D
-        p.sb, p.kv_len, p.causal, p.lse_layout, p.num_splits = sk.shape[0], sk.shape[1], 0, HYD_LSE_BQH, 1
-        self.pp = p
-        self.sp = {}
-        self.seq = {}
+        self.params, self.keep = {}, []
+        ws_bytes = 0
         for s in range(1, k.shape[1] + 1):
             sl = torch.full((B,), s, dtype=torch.int32, device=q.device)
-            spar = SuffixParams()
-            fill_suffix_params(spar, q, k, v, sl, self.out)
-            spar.n_partials = 1
-            spar.partials[0].out = self.pout.data_ptr()
-            spar.partials[0].lse = self.plse.data_ptr()
-            spar.partials[0].count = 1
-            spar.partials[0].is_f32 = 0
-            self.sp[s] = spar
-            self.seq[s] = sl
+            p = DecodeParams()
+            fill_suffix_params(p.suffix, q, k, v, sl, self.out)
+            p.n_levels = 1
+            _fill_level(p.levels[0], sk, sv, None, None, False, B)
+            ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(p)))
+            self.params[s] = p
+            self.keep.append(sl)
+        self.ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
+        for p in self.params.values():
+            p.workspace, p.workspace_bytes = self.ws.data_ptr(), ws_bytes
 
-    def prefix(self, stream):
-        self._lib.check(self.lib.hyd_prefix_attn_fwd(C.byref(self.pp), stream))
-
-    def suffix(self, s, stream):
-        self._lib.check(self.lib.hyd_suffix_attn_fwd(C.byref(self.sp[s]), stream))
+    def step(self, s, stream, ev_mid=None):
+        self._lib.check(self.lib.hyd_decode_attn_fused_timed(C.byref(self.params[s]), stream, ev_mid))
 
 
 def main():
@@ -148,12 +138,10 @@ def main():
         s = suffix_len(i)
         if ev is not None:
             ev[0].record()
-        ops.prefix(stream)
-        if ev is not None:
-            ev[1].record()
-        ops.suffix(s, stream)
-        if ev is not None:
+            ops.step(s, stream, ev[1].cuda_event)
             ev[2].record()
+        else:
+            ops.step(s, stream)
         if world > 1:
             dist.all_reduce(ar_buf)
 
@@ -162,6 +150,9 @@ def main():
     torch.cuda.synchronize()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    for ev in events:  # materialise the hipEvent_t handles (torch creates them lazily)
+        ev[1].record()
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -222,6 +213,12 @@ def main():
         },
     }
 
+    tr = REPO / "profiles" / "traffic_latest.json"
+    if tr.exists():  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        t = json.loads(tr.read_text())
+        res["roofline"]["traffic"] = t.get("suffix_hbm_bytes_per_launch")
+        res["roofline"]["traffic_source"] = t.get("source")
+        res["roofline_prefix"]["traffic"] = t.get("prefix_hbm_bytes_per_launch")
     if rank == 0 and world == 1 and not args.no_nosharing:
         res["nosharing"] = bench_nosharing(q, sk, sv, k, v, S, B * 1.0, res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -94,6 +94,7 @@ EXPORTS = {
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hyd_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeParams)]),
     "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
+    "hyd_decode_attn_fused_timed": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p, C.c_void_p]),
     "hyd_rope_append_decode": (C.c_int, [C.POINTER(RopeParams), C.c_void_p]),
     "hyd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

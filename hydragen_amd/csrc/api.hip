@@ -440,7 +440,9 @@ size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32
     return hyd_decode_workspace_bytes(&p);
 }
 
-int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
+int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) { return hyd_decode_attn_fused_timed(p, stream, nullptr); }
+
+int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* event_after_prefix) {
     if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
     if (p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return fail(HYD_ERR_BAD_ARG, "n_levels %d", p->n_levels);
     const hyd_suffix_params& sp = p->suffix;
@@ -496,6 +498,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         if ((rc = run_prefix(&pp, pl, /*merge=*/false, s))) return rc;
         ws += bytes;
     }
+    if (event_after_prefix) (void)hipEventRecord(static_cast<hipEvent_t>(event_after_prefix), s);
     if (sp.kv_len == 0) {
         // several levels, no unique keys: merge the level partials only (suffix contributes lse = -inf)
         hyd_suffix_params s0 = sp;

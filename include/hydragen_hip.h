@@ -158,6 +158,10 @@ typedef struct hyd_decode_params {
 
 size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);
 int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
+/* Measurement aid (bench.py): identical launches, plus hipEventRecord(event_after_prefix, stream) between
+ * the last prefix pass and the suffix pass so each kernel can be timed inside the fused call.  Not
+ * for use under graph capture. */
+int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* event_after_prefix);
 
 /* Upper bound helper mirroring SURVEY 8b's `hyd_workspace_bytes(shape...)`: bytes that
  * hyd_decode_attn_fused needs for n_levels uniform levels of the given shapes. */
