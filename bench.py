@@ -109,11 +109,15 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU; there is no CPU fallback for the product path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Self-test knobs (not used by the driver): HYD_BENCH_BACKEND=gloo + HYD_BENCH_ONE_DEVICE=1 run the
+    # N > 1 control flow with every rank on cuda:0 (RCCL refuses two ranks on one device).
+    backend = os.environ.get("HYD_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("HYD_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     B, P, S, D = args.batch, args.prefix, args.max_suffix, args.dim
     assert args.qheads % world == 0 and args.kvheads % world == 0, "heads must divide the TP degree (tp.py:43-46)"
@@ -143,8 +147,12 @@ def main():
         else:
             ops.step(s, stream)
         if world > 1:
-            dist.all_reduce(ar_buf)
+            if backend == "nccl":
+                dist.all_reduce(ar_buf)
+            else:  # gloo self-test: reduce a host copy
+                dist.all_reduce(ar_host)
 
+    ar_host = ar_buf.float().cpu() if (world > 1 and backend != "nccl") else None
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -165,7 +173,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -275,7 +283,8 @@ def cpu_baseline(B, P, Hq, Hkv, D, budget_s):
     """oracle/cpu_port_torch.py (README.md:377-461 restated) on the host cores; bounded sample."""
     from oracle import cpu_port_torch as port
 
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    cores = max(1, logical // 2) if logical > 16 else logical  # physical cores (SMT siblings only add contention)
     torch.set_num_threads(cores)
     S = 64
     # sample: a slice of the batch (all heads, full prefix, mid suffix), sized to the time budget

@@ -15,20 +15,30 @@ from torch import Tensor
 
 def attention(q: Tensor, k: Tensor, v: Tensor, kv_lens: Tensor | None = None):
     """README.md:381-391 'some fast attention primitive that also returns LSEs' in fp32 torch.
-    q [b, sq, hq, d]; k, v [b, sk, hkv, d] -> out [b, sq, hq, d], lse [b, sq, hq]."""
+    q [b, sq, hq, d]; k, v [b, sk, hkv, d] -> out [b, sq, hq, d], lse [b, sq, hq].
+    Many query rows per KV (the folded prefix pass) go through matmul; a handful of rows per sequence
+    (the decode suffix pass: b*hkv tiny problems) go through broadcast multiply-reduce, which is what a
+    CPU does well there (batched 1xD matmuls are overhead-bound)."""
     b, sq, hq, d = q.shape
     sk, hkv = k.shape[1], k.shape[2]
     g = hq // hkv
     qf = q.float().view(b, sq, hkv, g, d).permute(0, 2, 3, 1, 4).reshape(b, hkv, g * sq, d)
-    kf = k.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3)  # b hkv sk d
     vf = v.float().permute(0, 2, 1, 3)
-    s = torch.matmul(qf, kf.transpose(-1, -2)) * (d ** -0.5)  # [b, hkv, g*sq, sk]
+    small = g * sq <= 8
+    if small:
+        s = (qf[:, :, :, None, :] * kf[:, :, None, :, :]).sum(-1) * (d ** -0.5)  # b hkv rows sk
+    else:
+        s = torch.matmul(qf, kf.transpose(-1, -2)) * (d ** -0.5)
     if kv_lens is not None:
         mask = torch.arange(sk)[None, :] >= kv_lens[:, None]  # [b, sk]
         s = s.masked_fill(mask[:, None, None, :], float("-inf"))
     lse = torch.logsumexp(s, dim=-1)
     p = torch.exp(s - lse[..., None])
-    o = torch.matmul(p, vf)  # [b, hkv, g*sq, d]
+    if small:
+        o = (p[..., None] * vf[:, :, None, :, :]).sum(-2)
+    else:
+        o = torch.matmul(p, vf)  # [b, hkv, g*sq, d]
     o = o.view(b, hkv, g, sq, d).permute(0, 3, 1, 2, 4).reshape(b, sq, hq, d)
     lse = lse.view(b, hkv, g, sq).permute(0, 3, 1, 2).reshape(b, sq, hq)
     return o, lse

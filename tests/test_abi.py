@@ -92,6 +92,17 @@ def test_null_and_misaligned_pointers_rejected():
     assert lib.hyd_suffix_attn_fwd(C.byref(s), None) == -1 and "aligned" in lib.hyd_last_error_string().decode()
 
 
+def test_oversized_sequence_span_rejected_before_launch():
+    lib = _lib.load()
+    s = SuffixParams()
+    s.dtype, s.B, s.nq, s.Hq, s.Hkv, s.D = 1, 1, 1, 8, 8, 128
+    s.kv_len, s.k_tok_stride, s.v_tok_stride = 1 << 21, 1024, 1024          # 2^21 tokens * 2 KiB = 4 GiB per sequence
+    s.k_head_stride = s.v_head_stride = 128
+    s.q = s.k = s.v = s.out = 0x10000
+    assert lib.hyd_suffix_attn_fwd(C.byref(s), None) == -2
+    assert "2 GiB" in lib.hyd_last_error_string().decode()
+
+
 def test_decode_workspace_accounting():
     lib = _lib.load()
     sb = (C.c_int32 * 2)(1, 32)

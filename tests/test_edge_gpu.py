@@ -1,0 +1,87 @@
+"""-m gpu: edge cases of the operator surface -- maximum hierarchy depth, strided cache views, several
+queries per sequence, HIP-graph capture of the bare operator (what the reference's microbenchmark does,
+hydragen/benchmark_utils.py:140-170), head_dim 64 through the fused path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hydragen_oracle as O
+from tests.cases import _round
+from tests.gpu_util import assert_close, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, shape, dt):
+    return _round(rng.standard_normal(shape, dtype=np.float32), dt)
+
+
+def test_eight_shared_levels():
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    dt, rng = "f16", np.random.default_rng(21)
+    B, Hq, Hkv, D = 16, 8, 4, 128
+    q = _rand(rng, (B, 1, Hq, D), dt)
+    k, v = _rand(rng, (B, 9, Hkv, D), dt), _rand(rng, (B, 9, Hkv, D), dt)
+    sbs = [1, 1, 2, 2, 4, 8, 8, 16]
+    sks = [_rand(rng, (sb, 5 + 3 * i, Hkv, D), dt) for i, sb in enumerate(sbs)]
+    svs = [_rand(rng, (sb, 5 + 3 * i, Hkv, D), dt) for i, sb in enumerate(sbs)]
+    lens = np.asarray([9, 1, 4, 7] * 4, dtype=np.int32)
+    out = hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(x, dt) for x in sks], [dev(x, dt) for x in svs], dev(lens))
+    torch.cuda.synchronize()
+    assert_close(out.float().cpu().numpy(), O.hydragen_attention_nopad(q, k, v, sks, svs, lens), dt, "8 levels")
+    with pytest.raises(NotImplementedError):
+        hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(sks[0], dt)] * 9, [dev(svs[0], dt)] * 9, dev(lens))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_strided_cache_views_and_multi_query(dt):
+    """k/v handed over as views of a larger cache (llama.py:259-262 passes k_out[:bs]) and of a fused
+    kv buffer: only strides change, no copies.  nq = 2 queries per sequence with seq_lens."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    rng = np.random.default_rng(22)
+    B, nq, Hq, Hkv, D, S = 6, 2, 8, 2, 64, 20
+    q = _rand(rng, (B, nq, Hq, D), dt)
+    kv = _rand(rng, (B + 2, S + 12, 2, Hkv, D), dt)          # [maxB, maxS, (k|v), Hkv, D]
+    sk, sv = _rand(rng, (2, 37, Hkv, D), dt), _rand(rng, (2, 37, Hkv, D), dt)
+    lens = np.asarray([20, 3, 1, 17, 20, 8], dtype=np.int32)
+    tkv = dev(kv, dt)
+    tk, tv = tkv[:B, :S, 0], tkv[:B, :S, 1]                   # non-contiguous views
+    assert not tk.is_contiguous()
+    out = hydragen_attention_nopad(dev(q, dt), tk, tv, [dev(sk, dt)], [dev(sv, dt)], dev(lens))
+    torch.cuda.synchronize()
+    want = O.hydragen_attention_nopad(q, kv[:B, :S, 0], kv[:B, :S, 1], [sk], [sv], lens)
+    assert_close(out.float().cpu().numpy(), want, dt, "strided views, nq=2")
+
+
+def test_operator_under_hip_graph_capture():
+    """The library must be capture-safe: no allocation, no sync, current-stream launches only."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    dt, rng = "bf16", np.random.default_rng(23)
+    B, Hq, Hkv, D = 64, 8, 8, 128
+    q = dev(_rand(rng, (B, 1, Hq, D), dt), dt)
+    k, v = dev(_rand(rng, (B, 32, Hkv, D), dt), dt), dev(_rand(rng, (B, 32, Hkv, D), dt), dt)
+    sk, sv = dev(_rand(rng, (1, 300, Hkv, D), dt), dt), dev(_rand(rng, (1, 300, Hkv, D), dt), dt)
+    lens = torch.randint(1, 33, (B,), device="cuda:0", dtype=torch.int64)
+    eager = hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    # new data through the same captured graph (static input buffers, as llama.py:818-821)
+    q.copy_(torch.randn_like(q))
+    lens.copy_(torch.randint(1, 33, (B,), device="cuda:0"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens))
