@@ -257,6 +257,7 @@ int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts
     a.n_partials = n;
     if ((int64_t)p->kv_len * p->k_tok_stride * 2 >= (1ll << 31) || (int64_t)p->kv_len * p->v_tok_stride * 2 >= (1ll << 31))
         return fail(HYD_ERR_UNSUPPORTED, "unique K/V of one sequence spans >= 2 GiB (32-bit in-sequence offsets)");
+    if (p->Hkv > 4 * 65535 || a.rows > 8 * 65535) return fail(HYD_ERR_UNSUPPORTED, "too many kv heads / query rows for the suffix grid");
     int rc = launch_suffix(a, p->dtype, p->D, s);
     return rc ? fail(HYD_ERR_LAUNCH, "suffix kernel launch failed: hip error %d", rc) : HYD_OK;
 }

@@ -12,6 +12,8 @@
 // waves = consecutive kv heads of the same sequence, i.e. neighbouring 2*D-byte pieces of the same token
 // rows.  q.k partial dot products use v_dot2 and are reduced across the D/8 lanes with DPP adds; each
 // lane group runs its own online softmax over its keys; groups, then waves, are merged at the end.
+#include <type_traits>
+
 #include "hyd_kernels.h"
 
 namespace hyd {
@@ -62,10 +64,14 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane % LPK, ks = lane / LPK;
     const int wv = wave % WPU;
-    const int unit = blockIdx.x * (4 / WPU) + wave / WPU;
-    if (unit >= a.units) return;  // uniform per unit (all WPU waves of a unit leave together)
-    const int b = unit / a.Hkv, hk = unit % a.Hkv;
-    const int row0 = blockIdx.y * R;
+    // grid = (sequence, kv-head group, row chunk): no integer division on the way to (b, hk).  Sequence
+    // is the fastest-varying index on purpose: measured A/B on MI355X (same run, S = 128..256), spreading
+    // concurrently running workgroups over different sequences streams 5-10 % faster than walking the
+    // head groups of one sequence (whose rows share HBM channels).
+    const int b = blockIdx.x;
+    const int hk = blockIdx.y * (4 / WPU) + wave / WPU;
+    if (hk >= a.Hkv) return;  // uniform per unit (all WPU waves of a unit leave together)
+    const int row0 = blockIdx.z * R;
 
     int len = a.kv_len;
     if (a.sl32) len = a.sl32[b];
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
         const int row = row0 + r;
         u32x4 z = {0u, 0u, 0u, 0u};
         if (row < a.rows) {
-            const int iq = row / a.g, gq = row % a.g;
+            const int iq = a.nq == 1 ? 0 : row / a.g, gq = a.nq == 1 ? row : row % a.g;
             const uint16_t* qr = static_cast<const uint16_t*>(a.q) +
                                  (((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq) * D + sub * 8;
             qp[r] = *reinterpret_cast<const u32x4*>(qr);
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
         pl0[j] = 0.f;
         po0[j] = u32x4{0u, 0u, 0u, 0u};
         if (pre0 && r < R && row < a.rows) {
-            const int iq = row / a.g, gq = row % a.g;
+            const int iq = a.nq == 1 ? 0 : row / a.g, gq = a.nq == 1 ? row : row % a.g;
             const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;
             pl0[j] = a.partials[0].lse[ridx];
             po0[j] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.partials[0].out) + ridx * D + sub * 8);
@@ -124,11 +130,17 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
 
     const int niter = (len + KPI * WPU - 1) / (KPI * WPU);
     const float sc = a.scale_log2e;
-    for (int it = 0; it < niter; it += U) {
-        u32x4 kreg[U], vreg[U];
-        bool valid[U];
+    // One chunk = UU key iterations (UU wave instructions per tensor in flight): loads first, then scores,
+    // one online-softmax update, then the P.V accumulation.  Full chunks use UU = U; the tail (and every
+    // short sequence) runs one iteration at a time, so a wave never issues loads or arithmetic for
+    // iterations beyond ceil(len / keys-per-iteration) -- at small S the kernel is bound by exactly this
+    // per-wave instruction overhead, not by HBM.
+    auto chunk = [&](auto UU_C, int it) __attribute__((always_inline)) {
+        constexpr int UU = decltype(UU_C)::value;
+        u32x4 kreg[UU], vreg[UU];
+        bool valid[UU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             const int key = ((it + u) * WPU + wv) * KPI + ks;
             valid[u] = key < len;
             // never predicate the loads (a branch per load serialises them): clamp to the last valid key,
@@ -137,9 +149,9 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
             kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + ((unsigned)kc * krs + sub * 16)));
             vreg[u] = __builtin_nontemporal_load((gu32x4_p)(vbu + ((unsigned)kc * vrs + sub * 16)));
         }
-        float s[R][U];
+        float s[R][UU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UU; ++u) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float d = 0.f;
@@ -149,30 +161,29 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
                 s[r][u] = valid[u] ? d * sc : -INFINITY;
             }
         }
-        float mnew[R], alpha[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float cmax = s[r][0];
 #pragma unroll
-            for (int u = 1; u < U; ++u) cmax = fmaxf(cmax, s[r][u]);
-            mnew[r] = fmaxf(m[r], cmax);
-            const float ms = (mnew[r] == -INFINITY) ? 0.f : mnew[r];
-            alpha[r] = fast_exp2(m[r] - ms);
+            for (int u = 1; u < UU; ++u) cmax = fmaxf(cmax, s[r][u]);
+            const float mnew = fmaxf(m[r], cmax);
+            const float ms = (mnew == -INFINITY) ? 0.f : mnew;
+            const float alpha = fast_exp2(m[r] - ms);
             float ps = 0.f;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UU; ++u) {
                 s[r][u] = fast_exp2(s[r][u] - ms);  // p
                 ps += s[r][u];
             }
-            l[r] = l[r] * alpha[r] + ps;
-            m[r] = mnew[r];
+            l[r] = l[r] * alpha + ps;
+            m[r] = mnew;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r][j] *= alpha[r];
+            for (int j = 0; j < 8; ++j) acc[r][j] *= alpha;
         }
         // V is widened one key at a time, right where it is consumed (keeps the register footprint,
-        // hence the occupancy that hides HBM latency, independent of U)
+        // hence the occupancy that hides HBM latency, independent of UU)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             float vf[8];
             widen8<T>(vreg[u], vf);
 #pragma unroll
@@ -180,19 +191,46 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(s[r][u], vf[j], acc[r][j]);
         }
-    }
+    };
+    int it = 0;
+    for (; it + U <= niter; it += U) chunk(std::integral_constant<int, U>{}, it);
+    for (; it < niter; ++it) chunk(std::integral_constant<int, 1>{}, it);
 
     // ---- merge the KPI lane groups of the wave (butterfly: every lane ends with the total) -----
+    // Cross-lane exchange on the VALU (no LDS round trips): lanes xor 32 / xor 16 through
+    // v_permlane32_swap / v_permlane16_swap, which hand BOTH lanes the ordered pair (even side, odd side),
+    // so the merge is computed identically on both; lanes xor 8 (D = 64 only) through a DPP row rotate.
 #pragma unroll
     for (int off = LPK; off < 64; off <<= 1) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float m2 = __shfl_xor(m[r], off);
-            const float l2 = __shfl_xor(l[r], off);
-            float a2[8];
+            float m1, m2, l1, l2, a1v[8], a2v[8];
+            auto xchg = [&](float x, float& lo, float& hi) __attribute__((always_inline)) {
+                const int xi = __builtin_bit_cast(int, x);
+                if (off == 32) {
+                    auto p = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+                    lo = __builtin_bit_cast(float, (int)p[0]);
+                    hi = __builtin_bit_cast(float, (int)p[1]);
+                } else if (off == 16) {
+                    auto p = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+                    lo = __builtin_bit_cast(float, (int)p[0]);
+                    hi = __builtin_bit_cast(float, (int)p[1]);
+                } else {  // off == 8: partner inside the 16-lane DPP row
+                    lo = x;
+                    hi = dpp_f32<0x128>(x);  // row_ror:8
+                }
+            };
+            xchg(m[r], m1, m2);
+            xchg(l[r], l1, l2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a2[j] = __shfl_xor(acc[r][j], off);
-            merge_state(m[r], l[r], acc[r], m2, l2, a2);
+            for (int j = 0; j < 8; ++j) xchg(acc[r][j], a1v[j], a2v[j]);
+            const float mf = fmaxf(m1, m2);
+            const float ms = (mf == -INFINITY) ? 0.f : mf;
+            const float w1 = fast_exp2(m1 - ms), w2 = fast_exp2(m2 - ms);
+            m[r] = mf;
+            l[r] = l1 * w1 + l2 * w2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r][j] = a1v[j] * w1 + a2v[j] * w2;
         }
     }
 
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
     for (int r = 0; r < R; ++r) {
         const int row = row0 + r;
         if (row >= a.rows || ks != (r % KPI)) continue;
-        const int iq = row / a.g, gq = row % a.g;
+        const int iq = a.nq == 1 ? 0 : row / a.g, gq = a.nq == 1 ? row : row % a.g;
         const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;  // [B, nq, Hq]
         const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
         const float lse_s = l[r] > 0.f ? m[r] * kLn2 + __logf(l[r]) : -INFINITY;
@@ -294,10 +332,10 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
     const int row_chunks = (a.rows + R - 1) / R;
     const bool few_units = (int64_t)a.units * row_chunks < 2 * 256 * 4 && a.kv_len >= 64;
     if (few_units) {
-        dim3 grid(a.units, row_chunks);
+        dim3 grid(a.B, a.Hkv, row_chunks);
         hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 4>), grid, dim3(256), 0, s, a);
     } else {
-        dim3 grid((a.units + 3) / 4, row_chunks);
+        dim3 grid(a.B, (a.Hkv + 3) / 4, row_chunks);
         hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();
