@@ -85,3 +85,43 @@ def test_operator_under_hip_graph_capture():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_prefix_deferred_rescale_is_exact(dt, causal):
+    """The prefix kernel raises its running maximum lazily (only when a 32-key block exceeds it by more than
+    2^8) and then rescales O and l in a rarely taken branch.  Bounded random data never takes that branch
+    after the first block, so spike individual keys late in the sequence (raw q.k far above every other
+    score, at several block positions, twice in a row) and compare out AND lse with the float64 oracle."""
+    from hydragen_amd.flash import flash_attention
+
+    rng = np.random.default_rng(23)
+    b, sq, sk, hq, hkv, D = 1, 160, 1000, 4, 2, 128
+    q = _rand(rng, (b, sq, hq, D), dt)
+    k, v = _rand(rng, (b, sk, hkv, D), dt), _rand(rng, (b, sk, hkv, D), dt)
+    for pos, f in ((70, 5.0), (333, 9.0), (334, 14.0), (640, 20.0), (959, 28.0), (999, 40.0)):
+        k[:, pos] = _round(k[:, pos] * f, dt)
+    q[:, :, 0] = _round(np.abs(q[:, :, 0]) * np.sign(k[:, 959, 0])[:, None, :], dt)  # head 0: every row aligns with key 959
+    out, lse = flash_attention(dev(q, dt), dev(k, dt), dev(v, dt), causal=causal)
+    torch.cuda.synchronize()
+    want, wlse = O.flash_attention(q, k, v, causal=causal)
+    assert_close(out.float().cpu().numpy(), want, dt, "spiked keys: out")
+    assert (np.abs(lse.cpu().numpy() - wlse) <= 2e-3 + 1e-5 * np.abs(wlse)).all()
+
+
+@pytest.mark.parametrize("sk", [1, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 160, 255, 256, 257, 300, 511, 513])
+def test_prefix_lengths_around_block_boundaries(sk):
+    """Keys are staged in 32-key blocks (two per 64-key half of a 128-key tile) by bounds-checked DMA: every
+    length around those boundaries, D = 128 and 64, against the oracle."""
+    from hydragen_amd.flash import flash_attention
+
+    dt, rng = "bf16", np.random.default_rng(100 + sk)
+    for D, hq, hkv in ((128, 4, 2), (64, 2, 2)):
+        q = _rand(rng, (2, 70, hq, D), dt)
+        k, v = _rand(rng, (2, sk, hkv, D), dt), _rand(rng, (2, sk, hkv, D), dt)
+        out, lse = flash_attention(dev(q, dt), dev(k, dt), dev(v, dt))
+        torch.cuda.synchronize()
+        want, wlse = O.flash_attention(q, k, v)
+        assert_close(out.float().cpu().numpy(), want, dt, f"sk={sk} D={D}")
+        assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3

@@ -30,12 +30,16 @@ def torch_ref(q, ks, vs, lens=None):
     return o.view(b, hkv, g, nq, d).permute(0, 3, 1, 2, 4).reshape(b, nq, hq, d)
 
 
-def check(out, ref, dt, what):
+def check(out, ref, dt, what, pair=False):
+    """pair=True: `ref` is itself a kernel output rounded to `dt`, so two independent rounding noises add
+    (sqrt(2) x the bound that holds against an exact reference; measured vs fp64 at C2 shape: bf16 mean
+    rdiff 0.76-0.85 % per output, tools/errstat.py)."""
     out, ref = out.float(), ref.float()
     assert torch.isfinite(out).all(), what
     err = (out - ref).abs().max().item()
     rd = (2 * (out - ref).abs() / (out.abs() + ref.abs() + 1e-8)).mean().item()
-    assert err <= ATOL[dt] and rd <= RTOL_MEAN[dt], f"{what}: max abs {err:.3e} mean rdiff {rd:.3e}"
+    rtol = RTOL_MEAN[dt] * (2 ** 0.5 if pair else 1.0)
+    assert err <= ATOL[dt] and rd <= rtol, f"{what}: max abs {err:.3e} mean rdiff {rd:.3e}"
 
 
 def make(B, P_levels, S, Hq, Hkv, D, dtype, seed=0, ragged=True):
@@ -105,7 +109,7 @@ def test_c2_decomposed_equals_nosharing_kernel(dt):
     vt = torch.cat([svs[0].expand(q.shape[0], -1, -1, -1), v], 1).contiguous()
     # unique keys sit right after the prefix; padded tail is masked by seq_len
     ns, _ = flash_attention_seqlen(q, kt, vt, seq_len=(lens + P))
-    check(out, ns, dt, "decomposed vs no-sharing")
+    check(out, ns, dt, "decomposed vs no-sharing", pair=True)
 
 
 def test_c2_properties():
@@ -118,18 +122,18 @@ def test_c2_properties():
     # (1) permuting the shared keys (K and V together) changes nothing but the summation order
     perm = torch.randperm(sks[0].shape[1], device=DEV)
     out_p = hydragen_attention_nopad(q, k, v, [sks[0][:, perm].contiguous()], [svs[0][:, perm].contiguous()], seq_len=lens)
-    check(out_p, out, dt, "prefix permutation invariance")
+    check(out_p, out, dt, "prefix permutation invariance", pair=True)
     # (2) hierarchy consistency: one 2048-key level == two levels of 1024 keys
     h = sks[0].shape[1] // 2
     out_h = hydragen_attention_nopad(q, k, v, [sks[0][:, :h].contiguous(), sks[0][:, h:].contiguous()],
                                      [svs[0][:, :h].contiguous(), svs[0][:, h:].contiguous()], seq_len=lens)
-    check(out_h, out, dt, "two-level == one-level")
+    check(out_h, out, dt, "two-level == one-level", pair=True)
     # (3) the pieces: prefix (out, lse) + suffix (out, lse) merged by combine_lse == fused call
     B, _, Hq, D = q.shape
     po, pl = flash_attention(q.view(1, B, Hq, D), sks[0], svs[0])
     so, sl = flash_attention_seqlen(q, k, v, seq_len=lens)
     merged = combine_lse([po.view(B, 1, Hq, D), so], [pl.permute(0, 2, 1).reshape(B, 1, Hq).contiguous(), sl])
-    check(merged, out, dt, "unfused pieces == fused")
+    check(merged, out, dt, "unfused pieces == fused", pair=True)
     # (4) idempotence of the merge: combining a partial with itself returns it
     same = combine_lse([so, so], [sl, sl])
     assert (same.float() - so.float()).abs().max().item() <= 1e-2
