@@ -41,7 +41,7 @@ q = torch.randn(a.B, 1, a.Hq, a.D, device=dev, dtype=dt)
 if a.what == "prefix":
     for P in map(int, a.P.split(",")):
         sk = torch.randn(1, P, a.Hkv, a.D, device=dev, dtype=dt); sv = torch.randn_like(sk)
-        out = torch.empty_like(q); lse = torch.empty(a.B, 1, a.Hq, device=dev, dtype=torch.float32)
+        out = torch.empty_like(q); lse = torch.zeros(a.B * a.Hq + 64, device=dev, dtype=torch.float32)
         p = PrefixParams()
         p.q, p.k, p.v, p.out, p.lse = q.data_ptr(), sk.data_ptr(), sv.data_ptr(), out.data_ptr(), lse.data_ptr()
         p.k_group_stride, p.k_tok_stride, p.k_head_stride = sk.stride(0), sk.stride(1), sk.stride(2)
@@ -54,6 +54,13 @@ if a.what == "prefix":
         us = timeit(lambda: _lib.check(lib.hyd_prefix_attn_fwd(C.byref(p), stream)), a.iters)
         fl = 4.0 * a.B * a.Hq * P * a.D
         print(f"prefix P={P:6d}  {us:9.2f} us  {fl/us/1e6:8.1f} TFLOP/s  ({fl/us/1e6/2500*100:5.1f}% of 2.5PF)")
+        import os
+        if int(os.environ.get("HYD_DBG", "0")) & 64:  # ablation build: cycle stamps of one iteration, 8 waves of block 0
+            torch.cuda.synchronize()
+            ts = lse.view(torch.int32).flatten()[a.B * a.Hq:a.B * a.Hq + 64].cpu().view(8, 8)
+            for w in range(8):
+                d = [(int(ts[w, k]) - int(ts[w, 0])) & 0xffffffff for k in range(8)]
+                print(f"   wave {w}: slots0-3 {d[1]}  4-7 {d[2]-d[1]}  8-11 {d[3]-d[2]}  12-15 {d[4]-d[3]}  tail {d[5]-d[4]}  dma_wait {d[6]-d[5]}  barrier {d[7]-d[6]}  | iteration {d[7]}")
 else:
     Smax = max(map(int, a.S.split(",")))
     k = torch.randn(a.B, Smax, a.Hkv, a.D, device=dev, dtype=dt); v = torch.randn_like(k)

@@ -13,7 +13,7 @@ def main(path, tag):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if c in parts:
                 i = parts.index(c)
-                kern = "suffix" if "suffix_attn_kernel" in line else "prefix" if "prefix_attn_kernel" in line else None
+                kern = "suffix" if "suffix_attn_kernel" in line else "prefix" if "prefix_attn" in line else None
                 if kern:
                     vals[(kern, c)] = float(parts[i + 2])
     out = {

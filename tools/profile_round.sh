@@ -21,7 +21,7 @@ for C in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
   D=/tmp/prof_pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C -d $D -o run -- $CMD > /dev/null 2>$D.log
   DB=$(find $D -name '*.db' | head -1)
-  if [ -n "$DB" ]; then python $REPO/tools/rocprof_summary.py pmc $DB attn_kernel; else echo "# pass '$C' produced no db: $(tail -2 $D.log | tr '\n' ' ')"; fi
+  if [ -n "$DB" ]; then python $REPO/tools/rocprof_summary.py pmc $DB _attn_; else echo "# pass '$C' produced no db: $(tail -2 $D.log | tr '\n' ' ')"; fi
 done
 } > $OUT/${TAG}_pmc.txt
 python $REPO/tools/make_traffic.py $OUT/${TAG}_pmc.txt $TAG > $OUT/traffic_latest.json
