@@ -28,7 +28,14 @@ def _dtype_code(t: Tensor) -> int:
     raise NotImplementedError(f"hydragen_amd kernels take float16/bfloat16, got {t.dtype}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device (the raw accessor skips ~8 us of
+    Python per call; every launch of the library goes to this stream, so graph capture sees it)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
