@@ -168,3 +168,62 @@ def test_hydragen_vs_nosharing_and_flat_hierarchy(dtype):
         layer.self_attn.use_fused_decode = False
     _, c = model.generate(**kw)
     assert rdiff(torch.stack(a), torch.stack(c)).mean() < bound
+
+
+def _tp_gpu_worker(rank, world, port, shard_dir, ids_cpu, overrides_cpu, ret):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from hydragen_amd import tp, utils
+
+    # both ranks share the one GPU of the test box; the collective goes through gloo (RCCL needs one GPU per rank)
+    assert utils.maybe_init_dist(backend="gloo") == rank
+    model = tp.from_pretrained_tp(shard_dir, device=DEV)
+    ids = [x.to(DEV) for x in ids_cpu]
+    B, new = overrides_cpu.shape
+    model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=32,
+                       max_shared_batch_sizes=[x.shape[0] for x in ids], max_shared_seq_lengths=[x.shape[1] for x in ids])
+    out, logits = model.generate(input_ids=ids, seq_lens=None, num_return_sequences=B // ids[-1].shape[0], max_new_tokens=new,
+                                 temperature=0.0, return_logits=True, token_overrides=overrides_cpu.to(DEV))
+    if rank == 0:
+        ret.put(torch.stack(logits).float().cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_model_two_ranks_on_one_gpu(tmp_path):
+    """head-sharded model shell (apply_tp shards, per-rank KV caches with Hkv/2 heads, the HIP
+    operator on each rank's heads, all-reduce after o_proj and down_proj) reproduces the unsharded model's decode
+    logits.  World size 2 on the single GPU of the box, gloo collectives."""
+    import socket
+    import torch.multiprocessing as mp
+    from hydragen_amd import tp
+
+    dtype = torch.float16
+    model = make_model(dtype, head_dim=64)
+    tp.make_tp_files(model, tmp_path, num_splits=2)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    rnd = lambda *s: torch.randint(1, 512, s, device=DEV, generator=g)
+    ids, nret, new = [rnd(1, 37), rnd(2, 9)], 3, 5
+    B = ids[-1].shape[0] * nret
+    overrides = rnd(B, new)
+    model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=32,
+                       max_shared_batch_sizes=[x.shape[0] for x in ids], max_shared_seq_lengths=[x.shape[1] for x in ids])
+    _, logits = model.generate(input_ids=ids, seq_lens=None, num_return_sequences=nret, max_new_tokens=new,
+                               temperature=0.0, return_logits=True, token_overrides=overrides)
+    want = torch.stack(logits).float().cpu().numpy()
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, 2, port, str(tmp_path), [x.cpu() for x in ids], overrides.cpu(), ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    got = ret.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # two different summation orders of fp16 partial products (per-rank o_proj / down_proj halves, then the sum)
+    assert abs(got - want).max() < 0.05
