@@ -215,7 +215,7 @@ def main():
             "algorithmic_bytes_per_launch_mean": sum(suf_bytes) / args.steps,
         },
         "roofline_prefix": {
-            "kernel": "prefix_attn_kernel (batched-query MFMA pass)",
+            "kernel": "prefix_attn_pl_kernel (batched-query MFMA pass, software-pipelined)",
             "bound": "mfma", "achieved": pre_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": pre_tflops / MFMA_PEAK_TFLOPS, "flops_per_launch": pre_flops,
         },

@@ -122,18 +122,14 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
 
 // Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
 // `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
-// The prefix pass runs the software-pipelined kernel (prefix_attn_pl.hip).  Two earlier implementations stay
-// selectable for A/B measurements on hardware: HYD_PREFIX_IMPL=w8 (phase-separated, prefix_attn.hip) and
-// HYD_PREFIX_IMPL=p4 (1 wave per SIMD, prefix_attn_p4.hip).
+// The prefix pass runs the software-pipelined kernel (prefix_attn_pl.hip).  The earlier phase-separated kernel
+// (prefix_attn.hip) stays selectable with HYD_PREFIX_IMPL=w8 for A/B measurements on hardware.
 int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
-    static const int impl = [] {
+    static const bool w8 = [] {
         const char* e = getenv("HYD_PREFIX_IMPL");
-        if (e && !strcmp(e, "p4")) return 1;
-        if (e && !strcmp(e, "w8")) return 0;
-        return 2;
+        return e && !strcmp(e, "w8");
     }();
-    if (impl == 2) return launch_prefix_pl(a, dtype, D, causal, grid, s);
-    return impl ? launch_prefix_p4(a, dtype, D, causal, grid, s) : launch_prefix(a, dtype, D, causal, grid, s);
+    return w8 ? launch_prefix(a, dtype, D, causal, grid, s) : launch_prefix_pl(a, dtype, D, causal, grid, s);
 }
 
 int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s) {
