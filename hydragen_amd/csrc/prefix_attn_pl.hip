@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     constexpr int NLB = RB / 128;        // DMA instructions per wave per 32-key block per tensor
     constexpr int RPI = 1024 / RB;       // rows per DMA instruction
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* mlbuf = reinterpret_cast<float*>(smem + 512 * RB);  // [4][2][64], after the K/V rings
+    float* mlbuf = reinterpret_cast<float*>(smem + 512 * RB);  // [8 waves][2][64], after the K/V rings
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -444,24 +444,31 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
 #undef HYD_IC
 
     // ---- merge the two key halves through LDS, normalise, store --------------------------------
-    float l_tot = pair_sum(l_run);
-    f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [4 rw][NDB*4][64 lanes] of f32x4
-    if (kg == 1) {
+    // Both waves of a pair (same rows, key half 0 / 1) take part: the wave of key half h finalises the d blocks
+    // [h * NDB/2, (h+1) * NDB/2) and hands the other blocks (+ its m, l) to its partner through LDS.  A lane holds
+    // 4 consecutive d per (d block, q4); v_permlane32_swap pairs the two half-waves' groups so that each lane
+    // stores 16 contiguous bytes (row-per-lane stores are issue-bound: 4 instead of 16 per wave, on all 8 waves).
+    constexpr int HDB = NDB / 2;
+    const float l_tot = pair_sum(l_run);
+    f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [8 waves][HDB * 4][64 lanes] of f32x4
+    {
+        const int dbo = kg ? 0 : HDB;  // first d block handed over
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+        for (int i = 0; i < HDB; ++i)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                f32x4 x = {o[db][4 * q4], o[db][4 * q4 + 1], o[db][4 * q4 + 2], o[db][4 * q4 + 3]};
-                obuf[(rw * NDB * 4 + db * 4 + q4) * 64 + lane] = x;
+                const f32x16& ob = kg ? o[i] : o[HDB + i];
+                f32x4 x = {ob[4 * q4], ob[4 * q4 + 1], ob[4 * q4 + 2], ob[4 * q4 + 3]};
+                obuf[(wave * HDB * 4 + i * 4 + q4) * 64 + lane] = x;
             }
-        mlbuf[rw * 128 + lane] = m_run;
-        mlbuf[rw * 128 + 64 + lane] = l_tot;
+        (void)dbo;
+        mlbuf[wave * 128 + lane] = m_run;
+        mlbuf[wave * 128 + 64 + lane] = l_tot;
     }
     __syncthreads();
-    if (kg != 0) return;
-
-    const float m1 = mlbuf[rw * 128 + lane];
-    const float l1 = mlbuf[rw * 128 + 64 + lane];
+    const int pw = wave ^ 4;  // partner wave
+    const float m1 = mlbuf[pw * 128 + lane];
+    const float l1 = mlbuf[pw * 128 + 64 + lane];
     const float mf = fmaxf(m_run, m1);
     const float mfs = (mf == -INFINITY) ? 0.f : mf;
     const float a0 = fast_exp2(m_run - mfs), a1 = fast_exp2(m1 - mfs);
@@ -469,25 +476,43 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     const float inv = lf > 0.f ? 1.0f / lf : 0.f;
     const float w0 = a0 * inv, w1 = a1 * inv;
 
-    if (!rvalid) return;
     const int64_t obase = (int64_t)sp * a.out_split_stride + row_off;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+    for (int i = 0; i < HDB; ++i) {
+        const f32x16& ob = kg ? o[HDB + i] : o[i];
+        const int db = kg * HDB + i;
+        f32x4 x[4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 y = obuf[(rw * NDB * 4 + db * 4 + q4) * 64 + lane];
-            f32x4 x;
+            const f32x4 y = obuf[(pw * HDB * 4 + i * 4 + q4) * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = o[db][4 * q4 + j] * w0 + y[j] * w1;
-            const int d0 = 32 * db + 8 * q4 + 4 * hi;
-            if (a.out_f32) {
-                *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + obase + d0) = x;
-            } else {
-                u32x2 pk = {TR::pack2(x[0], x[1]), TR::pack2(x[2], x[3])};
-                *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.out) + obase + d0) = pk;
+            for (int j = 0; j < 4; ++j) x[q4][j] = ob[4 * q4 + j] * w0 + y[j] * w1;
+        }
+        if (a.out_f32) {
+            if (rvalid) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + obase + 32 * db + 8 * q4 + 4 * hi) = x[q4];
+            }
+        } else {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                // groups (2qp, 2qp+1): after the swaps the lower half-wave holds d [8*(2qp), +8), the upper [8*(2qp+1), +8)
+                u32x4 w;
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) {
+                    const unsigned ea = TR::pack2(x[2 * qp][2 * dw], x[2 * qp][2 * dw + 1]);
+                    const unsigned eb = TR::pack2(x[2 * qp + 1][2 * dw], x[2 * qp + 1][2 * dw + 1]);
+                    auto r2 = __builtin_amdgcn_permlane32_swap(ea, eb, false, false);
+                    w[dw] = r2[0];      // lower half: own group 2qp      | upper half: lower's group 2qp+1
+                    w[2 + dw] = r2[1];  // lower half: upper's group 2qp  | upper half: own group 2qp+1
+                }
+                if (rvalid)
+                    *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(a.out) + obase + 32 * db + 8 * (2 * qp + hi)) = w;
             }
         }
-    if (a.lse && hi == 0) {
+    }
+    if (a.lse && kg == 0 && hi == 0 && rvalid) {
         const float lse = lf > 0.f ? mf * kLn2 + __logf(lf) : -INFINITY;
         int64_t idx;
         if (a.lse_layout == HYD_LSE_BQH)
@@ -500,7 +525,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
 
 template <typename T, int D, bool CAUSAL, int ABL = 0>
 static int launch_prefix_pl_t(const PrefixArgs& a, int grid, hipStream_t s) {
-    constexpr size_t lds = 2 * 256 * (D * 2) + 4 * 128 * sizeof(float);
+    constexpr size_t lds = 2 * 256 * (D * 2) + 8 * 128 * sizeof(float);
     auto kern = prefix_attn_pl_kernel<T, D, CAUSAL, ABL>;
     static bool attr_set = false;  // idempotent; value never changes
     if (!attr_set) {
