@@ -76,6 +76,15 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* mlbuf = reinterpret_cast<float*>(smem + 512 * RB);  // [8 waves][2][64], after the K/V rings
 
+    unsigned tst[6] = {0, 0, 0, 0, 0, 0};
+    auto stampk = [&](int k) __attribute__((always_inline)) {
+        if constexpr ((ABL & 64) != 0) {
+            uint64_t t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            tst[k] = (unsigned)t;
+        }
+    };
+    stampk(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -398,19 +407,27 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     auto kw_of = [&](int b) { return kwave + (b >> 1) * 128 + (b & 1) * 32; };
     // Every iteration i = -1 .. NB runs the same code: stages whose block does not exist work on zeros /
     // fully masked scores (QK(NB) and SM(-1), SM(NB) are harmless, PV(-2), PV(-1) add P = 0 times finite V).
+    // Cold start: every workgroup of the chip fetches at once, so only what the first iteration needs is waited
+    // for (Q, K blocks 0 and 1); K block 2 and V block 0 are issued behind that wait and land during iterations
+    // -1 / 0; V slots 2 and 3 are zero-filled in LDS instead of being fetched.
     if (NB > 0) {
         dma_block(0, false);
         dma_block(1, false);
-        dma_block(2, false);
-        dma_block(0, true);
-        dma_block(2, true);  // slots 2 and 3 are read by PV(-2) / PV(-1) with P = 0: must hold finite data
-        dma_block(3, true);
+        // slots 2 and 3 of the V ring (= tile buffer 1) are read by PV(-2) / PV(-1) with P = 0: must hold finite data
+        for (int off = tid * 16; off < V_BYTES; off += 512 * 16)
+            *reinterpret_cast<u32x4*>(smem + V_OFF + V_BYTES + off) = u32x4{0u, 0u, 0u, 0u};
     }
     // Make the compiler wait for the Q fragments here, not (conservatively, with vmcnt(0)) inside the loop.
 #pragma unroll
     for (int c = 0; c < NC; ++c) asm volatile("" ::"v"(qf[c]));
+    stampk(1);
     dma_wait<0>();
+    if (NB > 0) {
+        dma_block(2, false);  // covered by the counted wait that ends iteration -1
+        dma_block(0, true);
+    }
     __syncthreads();
+    stampk(2);
     if (NB > 0) {
 #pragma unroll
         for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, slot_k(0));
@@ -448,6 +465,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     // [h * NDB/2, (h+1) * NDB/2) and hands the other blocks (+ its m, l) to its partner through LDS.  A lane holds
     // 4 consecutive d per (d block, q4); v_permlane32_swap pairs the two half-waves' groups so that each lane
     // stores 16 contiguous bytes (row-per-lane stores are issue-bound: 4 instead of 16 per wave, on all 8 waves).
+    stampk(3);
     constexpr int HDB = NDB / 2;
     const float l_tot = pair_sum(l_run);
     f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [8 waves][HDB * 4][64 lanes] of f32x4
@@ -466,6 +484,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         mlbuf[wave * 128 + 64 + lane] = l_tot;
     }
     __syncthreads();
+    stampk(4);
     const int pw = wave ^ 4;  // partner wave
     const float m1 = mlbuf[pw * 128 + lane];
     const float l1 = mlbuf[pw * 128 + 64 + lane];
@@ -521,6 +540,15 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
             idx = ((int64_t)gi * a.Hq + hq) * a.lse_q_stride + rtok;
         a.lse[(int64_t)sp * a.lse_split_stride + idx] = lse;
     }
+    if constexpr ((ABL & 64) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stampk(5);
+        if (blockIdx.x == 0 && lane < 6) {
+            unsigned tv = tst[0];
+            for (int q_ = 1; q_ < 6; ++q_) tv = lane == q_ ? tst[q_] : tv;
+            reinterpret_cast<unsigned*>(a.lse)[(size_t)a.B * a.nq * a.Hq + wave * 8 + lane] = tv;
+        }
+    }
 }
 
 template <typename T, int D, bool CAUSAL, int ABL = 0>
@@ -542,7 +570,7 @@ int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int gri
     if (a.dbg && dtype == HYD_BF16 && D == 128 && !causal) {
         switch (a.dbg) {
 #define HYD_ABL(N) case N: return launch_prefix_pl_t<BF16, 128, false, N>(a, grid, s);
-            HYD_ABL(1) HYD_ABL(2) HYD_ABL(4) HYD_ABL(5) HYD_ABL(8) HYD_ABL(12) HYD_ABL(13) HYD_ABL(16) HYD_ABL(29)
+            HYD_ABL(1) HYD_ABL(2) HYD_ABL(8) HYD_ABL(16) HYD_ABL(64)
 #undef HYD_ABL
             default: break;
         }

@@ -59,8 +59,8 @@ if a.what == "prefix":
             torch.cuda.synchronize()
             ts = lse.view(torch.int32).flatten()[a.B * a.Hq:a.B * a.Hq + 64].cpu().view(8, 8)
             for w in range(8):
-                d = [(int(ts[w, k]) - int(ts[w, 0])) & 0xffffffff for k in range(8)]
-                print(f"   wave {w}: slots0-3 {d[1]}  4-7 {d[2]-d[1]}  8-11 {d[3]-d[2]}  12-15 {d[4]-d[3]}  tail {d[5]-d[4]}  dma_wait {d[6]-d[5]}  barrier {d[7]-d[6]}  | iteration {d[7]}")
+                d = [(int(ts[w, k]) - int(ts[w, 0])) & 0xffffffff for k in range(6)]
+                print(f"   wave {w}: setup+issue {d[1]}  first wait+barrier {d[2]-d[1]}  loop {d[3]-d[2]}  merge write+barrier {d[4]-d[3]}  combine+stores {d[5]-d[4]}  | kernel {d[5]} ticks")
 else:
     Smax = max(map(int, a.S.split(",")))
     k = torch.randn(a.B, Smax, a.Hkv, a.D, device=dev, dtype=dt); v = torch.randn_like(k)
