@@ -85,6 +85,8 @@ int launch_prefix(const PrefixArgs& a, int dtype, int D, bool causal, int grid, 
 int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
 int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
+bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape);
+int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 int launch_combine(const CombineArgs& a, hipStream_t s);
 
 }  // namespace hyd

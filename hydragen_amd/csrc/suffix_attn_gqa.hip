@@ -1,0 +1,282 @@
+// Suffix pass for grouped-query shapes (nq * g >= 4 query rows per (sequence, kv head)): the same operator as
+// suffix_attn.hip -- attention of the unit's rows over the first seq_len[b] keys of the sequence's own cache
+// plus the fused LSE combine with the prefix partials -- but with the two contractions on the matrix cores.
+//
+// Replaces _fwd_kernel_splitK + _splitK_reduce (/root/reference/hydragen/flash.py:76-281,
+// hydragen/xformers_stuff.py:189-428) and combine_lse (hydragen/attention.py:21-174) for GQA configurations
+// such as the reference microbenchmark's default Hq = 8, Hkv = 1 (scripts/microbenchmark.py:136-138).
+//
+// Why a second kernel: with R rows per unit the wave-level dot-product kernel issues ~R * 12 VALU instructions
+// per 4 keys and stops being HBM-bound at R = 8 (measured 2.1 TB/s at B = 2048, Hq/Hkv = 8/1, S = 256).  Here a
+// wave owns one unit and walks its keys 32 at a time:
+//   K  : 16-byte bounds-checked buffer loads straight into MFMA A-operand layout (lane = key & 15, 8 dims per
+//        lane), no LDS; keys past seq_len come back as zeros and are masked
+//   S^T = K . Q^T      2 * D/32 x v_mfma_f32_16x16x32 (Q rows padded to 16, kept in registers)
+//   online softmax in base 2, one query row per lane & 15, 8 scores per lane, two cross-lane exchanges
+//   V  : LDS-DMA (buffer_load ... lds, zero fill past seq_len) into a swizzled 32-key tile, read back
+//        transposed with ds_read_b64_tr_b16
+//   O^T += V^T . P^T   D/16 x MFMA, P^T converted in registers (the contraction index is permuted to the
+//        accumulator layout, keys {4j..4j+3, 16+4j..}, so no data moves)
+// One wave per workgroup: producer and consumer of the LDS tile are the same wave, no barriers.
+#include "hyd_kernels.h"
+
+namespace hyd {
+
+namespace {
+
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<BF16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <>
+struct Mfma16<F16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_g;
+__device__ __forceinline__ u32x2 lds_tr16_g(unsigned lds_byte_addr) {
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_g)(uintptr_t)lds_byte_addr);
+    return __builtin_bit_cast(u32x2, t);
+}
+
+__device__ __forceinline__ u32x4 make_rsrc_g(const void* base, unsigned bytes) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+// 64 lanes x 16 B, global -> LDS [lds_dst, +1 KiB) (lane-linear image), zero fill past the resource's end
+__device__ __forceinline__ void dma16_g(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+                 : "memory");
+}
+// 16 B per lane into registers, same bounds check
+__device__ __forceinline__ u32x4 load16_g(u32x4 rsrc, unsigned voff, unsigned soff) {
+    u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return r;
+}
+
+// symmetric all-reduce over the 4 lanes {l, l^16, l^32, l^48} (same query row, the 4 key groups)
+__device__ __forceinline__ float quad_max(float x) {
+    int xi = __builtin_bit_cast(int, x);
+    auto p = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    x = fmaxf(__builtin_bit_cast(float, (int)p[0]), __builtin_bit_cast(float, (int)p[1]));
+    xi = __builtin_bit_cast(int, x);
+    auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    return fmaxf(__builtin_bit_cast(float, (int)q[0]), __builtin_bit_cast(float, (int)q[1]));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    int xi = __builtin_bit_cast(int, x);
+    auto p = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    x = __builtin_bit_cast(float, (int)p[0]) + __builtin_bit_cast(float, (int)p[1]);
+    xi = __builtin_bit_cast(int, x);
+    auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    return __builtin_bit_cast(float, (int)q[0]) + __builtin_bit_cast(float, (int)q[1]);
+}
+
+}  // namespace
+
+template <typename T, int D>
+__global__ __launch_bounds__(64) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+    using TR = Traits<T>;
+    constexpr int RB = D * 2;        // bytes per K/V row
+    constexpr int NCH = D / 32;      // 32-dim chunks of the QK^T contraction
+    constexpr int NDB = D / 16;      // 16-wide d blocks of O^T
+    constexpr int RPI = 1024 / RB;   // V rows per DMA instruction
+    constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key V tile
+    __shared__ __attribute__((aligned(1024))) char vtile[32 * RB];
+
+    const int lane = threadIdx.x;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int b = blockIdx.x, hk = blockIdx.y, row0 = blockIdx.z * 16;
+
+    int len = a.kv_len;
+    if (a.sl32) len = a.sl32[b];
+    else if (a.sl64) len = (int)a.sl64[b];
+    len = max(0, min(len, a.kv_len));
+
+    // ---- this lane's query row (B operand of S^T = K Q^T: column = row l15, 8 dims of every 32-dim chunk) ----
+    const int row = row0 + l15;
+    const bool rvalid = row < a.rows;
+    const int iq = a.nq == 1 ? 0 : (rvalid ? row / a.g : 0), gq = a.nq == 1 ? (rvalid ? row : 0) : (rvalid ? row % a.g : 0);
+    const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;  // [B, nq, Hq]
+    u32x4 qf[NCH];
+    {
+        const uint16_t* qr = static_cast<const uint16_t*>(a.q) + ridx * D + 8 * g4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            qf[c] = rvalid ? *reinterpret_cast<const u32x4*>(qr + 32 * c) : z;
+        }
+    }
+
+    // ---- K / V windows of this unit: rows [0, len) are in range, everything else reads as zero ------------------
+    const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
+    const u32x4 krs = make_rsrc_g(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs, (unsigned)len * k_ts2);
+    const u32x4 vrs = make_rsrc_g(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs, (unsigned)len * v_ts2);
+    // K fragment (A operand): key = l15 of a 16-key block, dims 32 c + 8 g4 .. + 8
+    const unsigned kvoff = (unsigned)l15 * k_ts2 + 16u * g4;
+    // V DMA: instruction i covers tile rows [i * RPI, +RPI); the XOR swizzle of the LDS image is applied to the source chunk
+    const int drow = (lane * 16) / RB, dcp = ((lane * 16) % RB) >> 4;
+    unsigned vvoff[NVD];
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) {
+        const int r_ = i * RPI + drow;
+        const int sw = D == 128 ? (r_ & 3) : ((r_ >> 1) & 1);
+        const int vch = (((dcp >> 2) ^ sw) << 2) | (dcp & 3);
+        vvoff[i] = (unsigned)r_ * v_ts2 + (unsigned)vch * 16u;
+    }
+    typedef const __attribute__((address_space(3))) char* lptr_c;
+    const unsigned vt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)vtile);
+    // V^T fragment (A operand of O^T += V^T P^T): d = 16 db + l15, keys {4 g4 + j} (half 0) / {16 + 4 g4 + j} (half 1);
+    // the 16-lane group reads the 4 x 16 block, lane l15 supplies row l15 >> 2, columns 4 (l15 & 3) .. + 4
+    const int trow = 4 * g4 + (l15 >> 2);
+    const int tsw = D == 128 ? (trow & 3) : ((trow >> 1) & 1);
+    unsigned vaddr[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        vaddr[db] = (unsigned)(uintptr_t)(lptr_c)(vtile + trow * RB + (((db >> 1) ^ tsw) << 6) + 32 * (db & 1) + 8 * (l15 & 3));
+
+    f32x4 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = a.scale_log2e;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int key0 = 0; key0 < len; key0 += 32) {
+        // all loads of the step first (K to registers, V to LDS), one wait; other waves of the CU hide the latency
+        const unsigned ksoff = (unsigned)key0 * k_ts2, vsoff = (unsigned)key0 * v_ts2;
+        u32x4 kf[2][NCH];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) kf[h][c] = load16_g(krs, kvoff + (unsigned)h * 16u * k_ts2 + 64u * c, ksoff);
+#pragma unroll
+        for (int i = 0; i < NVD; ++i) dma16_g(vrs, vvoff[i], vsoff, vt0 + i * 1024);
+        // wait for everything; names the K registers so that no MFMA is scheduled above the wait
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1])
+                     :
+                     : "memory");
+        if constexpr (NCH == 4)
+            asm volatile("" : "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+
+        f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            s0 = Mfma16<T>::run(kf[0][c], qf[c], s0);
+            s1 = Mfma16<T>::run(kf[1][c], qf[c], s1);
+        }
+        // scores of this lane: keys key0 + 4 g4 + i (s0) and key0 + 16 + 4 g4 + i (s1), query row l15
+        float p[8];
+        const int kb = key0 + 4 * g4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[i] = (kb + i < len) ? s0[i] * sc : -INFINITY;
+            p[4 + i] = (kb + 16 + i < len) ? s1[i] * sc : -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+        tmax = quad_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);  // finite: key0 < len guarantees one valid key per row
+        const float alpha = fast_exp2(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            p[i] = fast_exp2(p[i] - m_new);
+            ps += p[i];
+        }
+        ps = quad_sum(ps);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        const u32x4 pf = {TR::pack2(p[0], p[1]), TR::pack2(p[2], p[3]), TR::pack2(p[4], p[5]), TR::pack2(p[6], p[7])};
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const u32x2 t0 = lds_tr16_g(vaddr[db]);
+            const u32x2 t1 = lds_tr16_g(vaddr[db] + 16 * RB);
+            const u32x4 vf = {t0[0], t0[1], t1[0], t1[1]};
+            o[db] = Mfma16<T>::run(vf, pf, o[db] * alpha);
+        }
+        // the next step's DMA overwrites the tile: every transposing read above has returned (the MFMAs consumed them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- epilogue: normalise, merge with the prefix partials (attention.py:21-43), store ---------------------
+    if (!rvalid) return;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    const float lse_s = l_run > 0.f ? m_run * kLn2 + __logf(l_run) : -INFINITY;
+    if (a.lse && g4 == 0) a.lse[ridx] = lse_s;
+    float M = lse_s;
+    for (int i = 0; i < a.n_partials; ++i) M = fmaxf(M, a.partials[i].lse[ridx]);
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    const float ws = a.n_partials ? __expf(lse_s - Ms) : 1.0f;
+    float den = ws;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) o[db] *= inv * ws;
+    for (int i = 0; i < a.n_partials; ++i) {
+        const float w = __expf(a.partials[i].lse[ridx] - Ms);
+        den += w;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int d0 = 16 * db + 4 * g4;
+            f32x4 x;
+            if (a.partials[i].is_f32) {
+                x = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.partials[i].out) + ridx * D + d0);
+            } else {
+                const u32x2 u = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.partials[i].out) + ridx * D + d0);
+                x = f32x4{TR::lo(u[0]), TR::hi(u[0]), TR::lo(u[1]), TR::hi(u[1])};
+            }
+            o[db] += x * w;
+        }
+    }
+    const float dinv = a.n_partials ? (den > 0.f ? 1.0f / den : 0.f) : 1.0f;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const f32x4 x = o[db] * dinv;
+        const u32x2 pk = {TR::pack2(x[0], x[1]), TR::pack2(x[2], x[3])};
+        *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.out) + ridx * D + 16 * db + 4 * g4) = pk;
+    }
+}
+
+// Shapes-only eligibility (capture-safe): enough query rows per unit for the matrix cores to pay, enough units to
+// fill the chip with one wave each, and byte offsets inside a unit's cache that fit the 32-bit buffer addressing.
+bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
+    if (D != 64 && D != 128) return false;
+    const int64_t chunks = (a.rows + 15) / 16;
+    if (!any_shape && (a.rows < 4 || (int64_t)a.units * chunks < 1024)) return false;
+    const int64_t span = (int64_t)a.kv_len * (a.k_ts > a.v_ts ? a.k_ts : a.v_ts) * 2;
+    return span < (int64_t)1 << 31 && a.Hkv <= 65535 && chunks <= 65535;
+}
+
+template <typename T, int D>
+static int launch_gqa_t(const SuffixArgs& a, hipStream_t s) {
+    dim3 grid(a.B, a.Hkv, (a.rows + 15) / 16);
+    hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D>), grid, dim3(64), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s) {
+    if (dtype == HYD_F16) {
+        if (D == 128) return launch_gqa_t<F16, 128>(a, s);
+        if (D == 64) return launch_gqa_t<F16, 64>(a, s);
+    } else {
+        if (D == 128) return launch_gqa_t<BF16, 128>(a, s);
+        if (D == 64) return launch_gqa_t<BF16, 64>(a, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace hyd
