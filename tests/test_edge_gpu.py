@@ -125,3 +125,35 @@ def test_prefix_lengths_around_block_boundaries(sk):
         want, wlse = O.flash_attention(q, k, v)
         assert_close(out.float().cpu().numpy(), want, dt, f"sk={sk} D={D}")
         assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("D,Hq,Hkv,nq", [(128, 8, 1, 1), (64, 8, 2, 1), (128, 4, 1, 2), (128, 8, 1, 3)])
+def test_grouped_query_suffix_kernel(dt, D, Hq, Hkv, nq):
+    """Shapes that the dispatcher sends to the matrix-core suffix kernel (>= 4 query rows per (sequence, kv head),
+    >= 256 units): ragged lengths incl. 1, a 32-key boundary and the full cache; 4 / 8 / 24 rows per unit (the last
+    one needs two 16-row chunks); through `flash_attention_seqlen` (out + LSE) and through the fused operator with
+    one and two shared levels (epilogue merge)."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+    from hydragen_amd.flash import flash_attention_seqlen
+
+    rng = np.random.default_rng(31 + D + Hq + nq)
+    B, S = 256 // Hkv * (2 if Hkv == 2 else 1), 70
+    q = _rand(rng, (B, nq, Hq, D), dt)
+    k, v = _rand(rng, (B, S, Hkv, D), dt), _rand(rng, (B, S, Hkv, D), dt)
+    lens = rng.integers(1, S + 1, B).astype(np.int32)
+    lens[:6] = [1, 31, 32, 33, 64, S]
+    out, lse = flash_attention_seqlen(dev(q, dt), dev(k, dt), dev(v, dt), seq_len=dev(lens))
+    torch.cuda.synchronize()
+    want, wlse = O.flash_attention_seqlen(q, k, v, lens)
+    assert_close(out.float().cpu().numpy(), want, dt, "gqa suffix: out")
+    assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3
+    if nq == 1:
+        sks = [_rand(rng, (1, 45, Hkv, D), dt), _rand(rng, (4, 9, Hkv, D), dt)]
+        svs = [_rand(rng, (1, 45, Hkv, D), dt), _rand(rng, (4, 9, Hkv, D), dt)]
+        for n in (1, 2):
+            got = hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(x, dt) for x in sks[:n]],
+                                           [dev(x, dt) for x in svs[:n]], dev(lens))
+            torch.cuda.synchronize()
+            assert_close(got.float().cpu().numpy(), O.hydragen_attention_nopad(q, k, v, sks[:n], svs[:n], lens), dt,
+                         f"gqa suffix fused, {n} level(s)")
