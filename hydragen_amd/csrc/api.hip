@@ -62,11 +62,13 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
     const int64_t units = (int64_t)p->sb * p->Hkv * pl->row_blocks;
     int ns = p->num_splits;
     if (ns <= 0) {
-        // shapes-only heuristic: fill ~1.5 workgroups per CU, keep >= 256 keys per split
+        // shapes-only heuristic: the prefix kernel runs one workgroup per CU (128 KB of LDS), so aim for ONE round of
+        // at most kNumCU workgroups (a second, partly filled round costs a whole extra pass plus its fixed ~12 us);
+        // keep >= 256 keys per split
         ns = 1;
-        if (units < (3 * kNumCU) / 4) {
+        if (units <= kNumCU / 2) {
             const int max_by_len = p->kv_len / 256 > 0 ? p->kv_len / 256 : 1;
-            int want = (int)((3 * kNumCU / 2 + units - 1) / units);
+            const int want = (int)(kNumCU / units);
             ns = want < max_by_len ? want : max_by_len;
         }
     }

@@ -20,7 +20,7 @@ ap.add_argument("--Hq", type=int, default=32)
 ap.add_argument("--Hkv", type=int, default=32)
 ap.add_argument("--D", type=int, default=128)
 ap.add_argument("--iters", type=int, default=30)
-ap.add_argument("--splits", type=int, default=1)
+ap.add_argument("--splits", type=int, default=0, help="0 = the library's own split-KV plan")
 ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
 lib = _lib.load()
