@@ -256,9 +256,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
     if (D != 64 && D != 128) return false;
     const int64_t chunks = (a.rows + 15) / 16;
-    // measured on MI355X: 4 rows per unit is where the matrix cores win (g = 2 is still faster on the VALU kernel);
-    // below one wave per CU the VALU kernel's 4-waves-per-unit key split uses more of the chip
-    if (!any_shape && (a.rows < 4 || (int64_t)a.units * chunks < 256)) return false;
+    // measured on MI355X: 4 rows per unit is where the matrix cores win (g = 2 is still faster on the VALU kernel), at
+    // every unit count from 4 to 8192 (tools/kbench.py, HYD_SUFFIX_IMPL=valu|gqa)
+    if (!any_shape && a.rows < 4) return false;
     const int64_t span = (int64_t)a.kv_len * (a.k_ts > a.v_ts ? a.k_ts : a.v_ts) * 2;
     return span < (int64_t)1 << 31 && a.Hkv <= 65535 && chunks <= 65535;
 }
