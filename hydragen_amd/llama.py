@@ -488,10 +488,30 @@ class HydragenLlamaForCausalLM(nn.Module):
 
     # ---- construction -----------------------------------------------------------------------------
     @classmethod
-    def from_config(cls, config: LlamaConfig, dtype=torch.bfloat16, device="cuda", seed: int = 0, std: float = 0.02):
-        """Random-weight model of the given architecture (synthetic benchmarks / tests)."""
-        with torch.device(device):
-            model = cls(config)
+    def from_config(cls, config: LlamaConfig, dtype=torch.bfloat16, device="cuda", seed: int = 0, std: float = 0.02,
+                    tp_shard: Optional[tuple] = None):
+        """Random-weight model of the given architecture (synthetic benchmarks / tests).  `tp_shard=(rank, world)`
+        builds only that rank's tensor-parallel shard (tp.py:115-132) without ever materialising the full model."""
+        if tp_shard is not None:
+            from copy import deepcopy
+            from .tp import apply_tp
+
+            with torch.device("meta"):
+                model = cls(deepcopy(config))
+            apply_tp(model.model, rank=tp_shard[0], world_size=tp_shard[1])
+            model.to_empty(device=device)
+            c = model.config
+            model.model.rotary_emb = RotaryTable(c.hidden_size // c.num_attention_heads, c.max_position_embeddings,
+                                                 c.rope_theta, device=device)
+            for layer in model.model.layers:
+                layer.self_attn.rotary_emb = model.model.rotary_emb
+            with torch.no_grad():
+                for prm in model.parameters():
+                    if prm.ndim == 1:
+                        prm.fill_(1.0)  # RMSNorm gains
+        else:
+            with torch.device(device):
+                model = cls(config)
         model.to(dtype=dtype)
         model.model.rotary_emb.float()  # cos/sin tables stay fp32 (cast per use, like HF's rotary embedding)
         g = torch.Generator(device=device).manual_seed(seed)

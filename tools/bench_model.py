@@ -20,6 +20,7 @@ ap.add_argument("--new", type=int, default=128)
 ap.add_argument("--modes", default="hydragen,noattention")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--tp-slice", type=int, default=1, help="build rank 0's shard of an N-way tensor-parallel model (no collectives: per-GPU compute only)")
 a = ap.parse_args()
 
 cfg = LlamaConfig.llama2_7b() if a.model == "llama2-7b" else LlamaConfig.llama3_70b()
@@ -27,7 +28,8 @@ if a.layers:
     cfg.num_hidden_layers = a.layers
 cfg.max_position_embeddings = max(cfg.max_position_embeddings, a.prefix + a.new + 16)
 dev = "cuda:0"
-model = HydragenLlamaForCausalLM.from_config(cfg, dtype=torch.bfloat16, device=dev, seed=0)
+model = HydragenLlamaForCausalLM.from_config(cfg, dtype=torch.bfloat16, device=dev, seed=0,
+                                             tp_shard=(0, a.tp_slice) if a.tp_slice > 1 else None)
 model.graph(not a.no_graph)
 prompt = torch.randint(1, cfg.vocab_size, (1, a.prefix), device=dev)
 
