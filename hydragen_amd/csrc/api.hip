@@ -118,8 +118,12 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->split_len = pl.split_len;
     a->lse_q_stride = pl.qpg;
     a->scale_log2e = (1.0f / sqrtf((float)p->D)) * kLog2e;
+#ifdef HYD_ABLATION_BUILD
     static const int dbg = getenv("HYD_DBG") ? atoi(getenv("HYD_DBG")) : 0;  // timing experiments only
     a->dbg = dbg;
+#else
+    a->dbg = 0;
+#endif
 }
 
 // Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if

@@ -23,7 +23,7 @@ struct PrefixArgs {
     int32_t row_blocks, nsplit, split_len;
     int32_t lse_layout, out_f32;
     float scale_log2e;
-    int32_t dbg;  // development only (HYD_DBG env): bit0 skip in-loop DMA, bit1 skip QK, bit2 skip SM, bit3 skip PV
+    int32_t dbg;  // 0 in product builds; HYD_ABLATION_BUILD reads HYD_DBG to pick a timing-ablation variant of a prefix kernel
 };
 
 struct PartialDev {

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // compute roles: rw = 32-row sub-block, kg = key half.  DMA roles (kgd) are fixed by wave index.
-    const int kg = (a.dbg & 16) ? (wave & 1) : (wave >> 2);
-    const int rw = (a.dbg & 16) ? (wave >> 1) : (wave & 3);
+    const int kg = wave >> 2;
+    const int rw = wave & 3;
     const int kgd = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
 
