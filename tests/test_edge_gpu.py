@@ -157,3 +157,21 @@ def test_grouped_query_suffix_kernel(dt, D, Hq, Hkv, nq):
             torch.cuda.synchronize()
             assert_close(got.float().cpu().numpy(), O.hydragen_attention_nopad(q, k, v, sks[:n], svs[:n], lens), dt,
                          f"gqa suffix fused, {n} level(s)")
+
+
+def test_repeated_launches_are_bit_identical():
+    """No atomics anywhere on the path, so every launch must reproduce the same bits; a difference would mean a
+    race (LDS ring slot reused too early, a DMA not waited for, a missing barrier) that a tolerance check can miss.
+    Shapes cover the pipelined prefix kernel (full tiles, a ragged tail, split-KV), the dot-product suffix kernel
+    and the matrix-core suffix kernel, back to back so that launches overlap their tails."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    r = lambda *s: torch.randn(*s, device="cuda:0", dtype=torch.bfloat16, generator=g)
+    for B, P, S, Hq, Hkv in ((512, 2048, 33, 8, 8), (256, 1000, 70, 8, 1), (16, 4097, 5, 16, 4), (1024, 300, 129, 4, 4)):
+        q, k, v, sk, sv = r(B, 1, Hq, 128), r(B, S, Hkv, 128), r(B, S, Hkv, 128), r(1, P, Hkv, 128), r(1, P, Hkv, 128)
+        lens = torch.randint(1, S + 1, (B,), device="cuda:0", generator=g, dtype=torch.int32)
+        outs = [hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens) for _ in range(40)]
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16)), (B, P, S, Hq, Hkv)
