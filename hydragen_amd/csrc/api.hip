@@ -292,10 +292,42 @@ void level_to_prefix(const hyd_decode_params* p, int i, hyd_prefix_params* pp) {
     pp->num_splits = 0;
 }
 
+// A shared level whose groups are small (few query rows per (group, kv head), short prefix) wastes the prefix
+// kernel: one 512-thread workgroup with ~12 us of fixed cost per (group, head) for a fraction of a 128 x 128 tile
+// (C4's second level, 32 groups x 32 queries x 64 keys: 1024 workgroups = 4 rounds = 52 us for 1 GFLOP).  Such a
+// level is the matrix-core suffix kernel's problem with "sequence" = group: nq' = per * nq query tokens per group
+// over the group's P keys, one wave per (group, kv head, 16-row chunk).  Shapes-only decision (capture-safe).
+bool level_is_small(const hyd_prefix_params& pp, const PrefixPlan& pl) {
+    static const bool off = [] {
+        const char* e = getenv("HYD_LEVEL_IMPL");
+        return e && !strcmp(e, "prefix");
+    }();
+    if (off || pp.cu_seqlens_k || pp.cu_seqlens_q || pp.causal) return false;
+    if (pp.D != 64 && pp.D != 128) return false;
+    const int64_t rows = (int64_t)pl.qpg * pl.g;  // query rows per (group, kv head)
+    if (rows > 64 || pp.kv_len > 1024) return false;
+    const int64_t ts = pp.k_tok_stride > pp.v_tok_stride ? pp.k_tok_stride : pp.v_tok_stride;
+    return (int64_t)pp.kv_len * ts * 2 < ((int64_t)1 << 31) && pp.Hkv <= 65535;
+}
+
+int run_level_small(const hyd_prefix_params& pp, const PrefixPlan& pl, void* out, float* lse, hipStream_t s) {
+    SuffixArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = pp.q; a.k = pp.k; a.v = pp.v; a.out = out; a.lse = lse;
+    a.k_bs = pp.k_group_stride; a.k_ts = pp.k_tok_stride; a.k_hs = pp.k_head_stride;
+    a.v_bs = pp.v_group_stride; a.v_ts = pp.v_tok_stride; a.v_hs = pp.v_head_stride;
+    a.B = pp.sb; a.nq = pl.qpg; a.Hq = pp.Hq; a.Hkv = pp.Hkv; a.g = pl.g; a.kv_len = pp.kv_len;
+    a.rows = pl.qpg * pl.g;
+    a.units = pp.sb * pp.Hkv;
+    a.scale_log2e = (1.0f / sqrtf((float)pp.D)) * kLog2e;
+    const int rc = launch_suffix_gqa(a, pp.dtype, pp.D, s);
+    return rc ? fail(HYD_ERR_LAUNCH, "small-level kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
 // per-level workspace: nsplit == 1 -> one dtype slice + lse; nsplit > 1 -> fp32 slices (prefix_ws_bytes)
 size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl) {
     const size_t rows = (size_t)pp.B * pp.nq * pp.Hq;
-    if (pl.nsplit > 1) return prefix_ws_bytes(&pp, pl);
+    if (pl.nsplit > 1 && !level_is_small(pp, pl)) return prefix_ws_bytes(&pp, pl);
     return align_up(rows * pp.D * 2, 256) + align_up(rows * 4, 256);
 }
 
@@ -484,7 +516,8 @@ int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* 
         if ((rc = check_prefix_ptrs(&pp))) return rc;
         if (pp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "level %d has kv_len == 0", i);
         const size_t bytes = level_ws_bytes(pp, pl);
-        if (pl.nsplit == 1) {
+        const bool small = level_is_small(pp, pl);
+        if (pl.nsplit == 1 || small) {
             pp.out = ws;
             pp.lse = reinterpret_cast<float*>(ws + align_up(rows * sp.D * 2, 256));
             parts[i].out = pp.out;
@@ -499,7 +532,9 @@ int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* 
             parts[i].count = pl.nsplit;
             parts[i].is_f32 = 1;
         }
-        if ((rc = run_prefix(&pp, pl, /*merge=*/false, s))) return rc;
+        if (small) rc = run_level_small(pp, pl, const_cast<void*>(parts[i].out), const_cast<float*>(parts[i].lse), s);
+        else rc = run_prefix(&pp, pl, /*merge=*/false, s);
+        if (rc) return rc;
         ws += bytes;
     }
     if (event_after_prefix) (void)hipEventRecord(static_cast<hipEvent_t>(event_after_prefix), s);
