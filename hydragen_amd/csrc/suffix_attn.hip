@@ -283,8 +283,16 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
         } else {
             const int i0 = pre0 ? 1 : 0;  // partial 0 already sits in registers
             const float l0 = pl0[r / KPI];
+            // The remaining partials (split-KV slices, further levels) are read four at a time with clamped indices,
+            // so that a batch's loads are all in flight together instead of one memory latency per partial.
+            const int np = a.n_partials;
             float M = pre0 ? fmaxf(lse_s, l0) : lse_s;
-            for (int i = i0; i < a.n_partials; ++i) M = fmaxf(M, a.partials[i].lse[ridx]);
+            for (int i = i0; i < np; i += 4) {
+                float lv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lv[j] = a.partials[min(i + j, np - 1)].lse[ridx];
+                M = fmaxf(fmaxf(M, fmaxf(lv[0], lv[1])), fmaxf(lv[2], lv[3]));
+            }
             const float Ms = (M == -INFINITY) ? 0.f : M;
             const float ws = __expf(lse_s - Ms);
             float den = ws;
@@ -298,25 +306,49 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
             }
-            for (int i = i0; i < a.n_partials; ++i) {
-                const float w = __expf(a.partials[i].lse[ridx] - Ms);
-                den += w;
-                float pv[8];
-                if (a.partials[i].is_f32) {
-                    const float* po = static_cast<const float*>(a.partials[i].out) + ridx * D + sub * 8;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(po);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(po + 4);
+            for (int i = i0; i < np;) {
+                // a batch = up to 4 consecutive partials of the same element type (slices of one level are adjacent)
+                const bool f32 = a.partials[i].is_f32 != 0;
+                int cnt = 1;
+                while (cnt < 4 && i + cnt < np && (a.partials[i + cnt].is_f32 != 0) == f32) ++cnt;
+                float lw[4];
+                float pv[4][8];
+                if (f32) {
+                    f32x4 x0[4], x1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        pv[j] = x0[j];
-                        pv[4 + j] = x1[j];
+                        const PartialDev& pd = a.partials[i + min(j, cnt - 1)];
+                        const float* po = static_cast<const float*>(pd.out) + ridx * D + sub * 8;
+                        lw[j] = pd.lse[ridx];
+                        x0[j] = *reinterpret_cast<const f32x4*>(po);
+                        x1[j] = *reinterpret_cast<const f32x4*>(po + 4);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pv[j][e] = x0[j][e];
+                            pv[j][4 + e] = x1[j][e];
+                        }
                 } else {
-                    const uint16_t* po = static_cast<const uint16_t*>(a.partials[i].out) + ridx * D + sub * 8;
-                    widen8<T>(*reinterpret_cast<const u32x4*>(po), pv);
+                    u32x4 x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const PartialDev& pd = a.partials[i + min(j, cnt - 1)];
+                        lw[j] = pd.lse[ridx];
+                        x[j] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(pd.out) + ridx * D + sub * 8);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) widen8<T>(x[j], pv[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
+                for (int j = 0; j < 4; ++j) {
+                    const float w = j < cnt ? __expf(lw[j] - Ms) : 0.f;
+                    den += w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) num[e] = __builtin_fmaf(w, pv[j][e], num[e]);
+                }
+                i += cnt;
             }
             const float dinv = den > 0.f ? 1.0f / den : 0.f;
 #pragma unroll

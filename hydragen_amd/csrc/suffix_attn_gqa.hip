@@ -219,28 +219,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     const float lse_s = l_run > 0.f ? m_run * kLn2 + __logf(l_run) : -INFINITY;
     if (a.lse && g4 == 0) a.lse[ridx] = lse_s;
+    // partials are read four at a time with clamped indices: a batch's loads are all in flight together (a split-KV
+    // prefix level hands over up to 16 fp32 slices)
+    const int np = a.n_partials;
     float M = lse_s;
-    for (int i = 0; i < a.n_partials; ++i) M = fmaxf(M, a.partials[i].lse[ridx]);
+    for (int i = 0; i < np; i += 4) {
+        float lv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lv[j] = a.partials[min(i + j, np - 1)].lse[ridx];
+        M = fmaxf(fmaxf(M, fmaxf(lv[0], lv[1])), fmaxf(lv[2], lv[3]));
+    }
     const float Ms = (M == -INFINITY) ? 0.f : M;
-    const float ws = a.n_partials ? __expf(lse_s - Ms) : 1.0f;
+    const float ws = np ? __expf(lse_s - Ms) : 1.0f;
     float den = ws;
 #pragma unroll
     for (int db = 0; db < NDB; ++db) o[db] *= inv * ws;
-    for (int i = 0; i < a.n_partials; ++i) {
-        const float w = __expf(a.partials[i].lse[ridx] - Ms);
-        den += w;
+    for (int i = 0; i < np; i += 2) {
+        // two partials per step: their 2 * D/16 row pieces are all requested before the first one is used
+        const int i1 = min(i + 1, np - 1);
+        const float w0 = __expf(a.partials[i].lse[ridx] - Ms);
+        const float w1 = i + 1 < np ? __expf(a.partials[i1].lse[ridx] - Ms) : 0.f;
+        den += w0 + w1;
+        f32x4 x0[NDB], x1[NDB];
+        auto fetch = [&](const PartialDev& pd, f32x4(&x)[NDB]) __attribute__((always_inline)) {
+            if (pd.is_f32) {
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            const int d0 = 16 * db + 4 * g4;
-            f32x4 x;
-            if (a.partials[i].is_f32) {
-                x = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.partials[i].out) + ridx * D + d0);
+                for (int db = 0; db < NDB; ++db)
+                    x[db] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(pd.out) + ridx * D + 16 * db + 4 * g4);
             } else {
-                const u32x2 u = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.partials[i].out) + ridx * D + d0);
-                x = f32x4{TR::lo(u[0]), TR::hi(u[0]), TR::lo(u[1]), TR::hi(u[1])};
+                u32x2 u[NDB];
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+                    u[db] = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(pd.out) + ridx * D + 16 * db + 4 * g4);
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) x[db] = f32x4{TR::lo(u[db][0]), TR::hi(u[db][0]), TR::lo(u[db][1]), TR::hi(u[db][1])};
             }
-            o[db] += x * w;
-        }
+        };
+        fetch(a.partials[i], x0);
+        fetch(a.partials[i1], x1);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[db] += x0[db] * w0 + x1[db] * w1;
     }
     const float dinv = a.n_partials ? (den > 0.f ? 1.0f / den : 0.f) : 1.0f;
 #pragma unroll
