@@ -227,3 +227,64 @@ def test_tensor_parallel_model_two_ranks_on_one_gpu(tmp_path):
         assert p.exitcode == 0
     # two different summation orders of fp16 partial products (per-rank o_proj / down_proj halves, then the sum)
     assert abs(got - want).max() < 0.05
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_readme_cache_workflows(graph):
+    """The finer-grained control flows of the reference README (README.md:183-289): (a) shared_cache_op="extend" on
+    the first generate, later calls reuse the cached prompt through `starting_logits`; (b) manual `append_shared` +
+    `starting_logits`; both must give the logits of a plain causal transformer over prompt + forced tokens, and the
+    cache bookkeeping (`get_num_used_shared_caches`, `empty_shared_cache`, `truncate_shared_caches`) must follow."""
+    from hydragen_amd.llama import SharedCacheOp
+
+    dtype = torch.float16
+    model = make_model(dtype, head_dim=64)
+    model.graph(graph)
+    g = torch.Generator(device=DEV).manual_seed(17)
+    rnd = lambda *s: torch.randint(1, 512, s, device=DEV, generator=g)
+    prompt, bs, new = rnd(1, 29), 4, 5
+    model.setup_caches(max_unique_batch_size=bs, max_unique_seq_length=32, max_shared_batch_sizes=[1, 2],
+                       max_shared_seq_lengths=[29, 11])
+
+    def check(logits, overrides, parts):
+        for j in range(bs):
+            full = torch.cat(parts(j) + [overrides[j, : new - 1]])[None]
+            ref = ref_logits(model, full)[0]
+            got = torch.stack([l[j] for l in logits])
+            assert (got - ref[full.shape[1] - new :]).abs().max() < 0.75
+
+    # (a) extend, then reuse
+    ov1 = rnd(bs, new)
+    _, logits = model.generate(input_ids=prompt, num_return_sequences=bs, max_new_tokens=new, temperature=0.0,
+                               return_logits=True, shared_cache_op=SharedCacheOp.EXTEND, token_overrides=ov1)
+    assert model.get_num_used_shared_caches() == 1
+    check(logits, ov1, lambda j: [prompt[0]])
+    starting = logits[0][0:1]
+    for _ in range(2):
+        ov = rnd(bs, new)
+        _, lg = model.generate(starting_logits=starting, num_return_sequences=bs, max_new_tokens=new, temperature=0.0,
+                               return_logits=True, token_overrides=ov)
+        assert model.get_num_used_shared_caches() == 1  # "preserve" keeps the prompt, adds nothing
+        check(lg, ov, lambda j: [prompt[0]])
+    # a second level on top of the kept prompt, removed again after the call ("preserve")
+    lvl2, ov = rnd(2, 11), rnd(bs, new)
+    _, lg = model.generate(input_ids=lvl2, num_return_sequences=bs // 2, max_new_tokens=new, temperature=0.0,
+                           return_logits=True, token_overrides=ov)
+    assert model.get_num_used_shared_caches() == 1
+    check(lg, ov, lambda j: [prompt[0], lvl2[j // 2]])
+    model.empty_shared_cache()
+    assert model.get_num_used_shared_caches() == 0
+
+    # (b) manual cache operations
+    prefill = model.append_shared(input_ids=prompt)
+    assert model.get_num_used_shared_caches() == 1
+    ov = rnd(bs, new)
+    _, lg = model.generate(starting_logits=prefill[:, -1], num_return_sequences=bs, max_new_tokens=new, temperature=0.0,
+                           return_logits=True, token_overrides=ov)
+    check(lg, ov, lambda j: [prompt[0]])
+    model.append_shared(input_ids=lvl2)
+    assert model.get_num_used_shared_caches() == 2
+    model.truncate_shared_caches(1)
+    assert model.get_num_used_shared_caches() == 1
+    model.empty_shared_cache()
+    assert model.get_num_used_shared_caches() == 0
