@@ -55,28 +55,6 @@ __device__ __forceinline__ void dma16(const char* gsrc, const char* lds_dst) {
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// 2*NDB transposing reads (one 16-key slot of the V^T operand) issued from inline asm with immediate
-// offsets; results are only valid after the matching tr_retire().
-template <int NDB, int OFF0, int OFF1>
-__device__ __forceinline__ void tr_issue(const unsigned (&va)[NDB], u32x2 (&r)[2 * NDB]) {
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                     : "=&v"(r[2 * db]), "=&v"(r[2 * db + 1])
-                     : "v"(va[db]), "i"(OFF0), "i"(OFF1));
-}
-// wait until at most PENDING LDS operations are outstanding; names the registers it retires so that
-// nothing consumes them early (LDS data returns in order), then pins the order for the MFMAs (rule 18).
-template <int NDB, int PENDING>
-__device__ __forceinline__ void tr_retire(u32x2 (&c)[2 * NDB]) {
-    if constexpr (NDB == 4)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]),
-                     "+v"(c[6]), "+v"(c[7]) : "i"(PENDING));
-    else
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "i"(PENDING));
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 // ABL: development-only ablation mask (bit0 no in-loop DMA, bit1 no QK, bit2 no softmax, bit3 no PV);
 // only ABL = 0 is ever used for results.
 template <typename T, int D, bool CAUSAL, int ABL = 0>

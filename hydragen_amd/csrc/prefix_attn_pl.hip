@@ -245,10 +245,8 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     for (int i = 0; i < 2; ++i) P0[i] = P1[i] = u32x4{0u, 0u, 0u, 0u};
 
     // ---- one pipeline iteration i: QK(i+1) | SM(i) | PV(i-1) -------------------------------------------
-    // KOFF / VOFF: compile-time ring-slot byte offsets of K block i+1 and V block i-1 (fast path), to which
-    // the runtime koff_rt / voff_rt are added (the slow path passes 0 constants and runtime offsets);
-    // NKOFF / NVOFF (+ nko_rt / nvo_rt): the same for iteration i+1, whose first fragments are prefetched
-    // in the tail of this one.
+    // KOFF / VOFF: compile-time ring-slot byte offsets of K block i+1 and V block i-1;
+    // NKOFF / NVOFF: the same for iteration i+1, whose first fragments are prefetched in the tail of this one.
     // FL: bit0 QK, bit1 SM, bit2 PV, bit3 the softmax may need masking, bit4 / bit5: iteration i+1 has QK / PV.
     // DM: 0 no DMA; 1: K block i+4 and V block i+2 through the buffer resources krs / vrs into ring slots
     //     kslot / vslot (byte offsets), spread between the MFMAs.
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         return lds_tr16_pl(vaddr[p % NDB] + off + (16 * (p / NDB) + 8 * h) * RB);
     };
     auto iter = [&](auto KOFF_C, auto VOFF_C, auto NKOFF_C, auto NVOFF_C, auto FL_C, auto DM_C, f32x16& Sw, f32x16& Sr,
-                    u32x4(&Pw)[2], u32x4(&Pr)[2], int kw, bool bvalid, int koff_rt, int voff_rt, int nko_rt, int nvo_rt,
+                    u32x4(&Pw)[2], u32x4(&Pr)[2], int kw, bool bvalid,
                     u32x4 krs, u32x4 vrs, int kslot, int vslot) __attribute__((always_inline)) {
         constexpr int KOFF = decltype(KOFF_C)::value;
         constexpr int VOFF = decltype(VOFF_C)::value;
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         constexpr int NPV = 2 * NDB;        // PV MFMAs (2 key slots x NDB d blocks)
         constexpr int NSLOT = NC + NPV;     // MFMA slots; QK and PV alternate
         constexpr int NG = 16;              // VALU groups of the softmax
-        auto ldk = [&](int c) -> u32x4 { return ldk_at(c, koff_rt + KOFF); };
-        auto ldv = [&](int p, int h) -> u32x2 { return ldv_at(p, h, voff_rt + VOFF); };
+        auto ldk = [&](int c) -> u32x4 { return ldk_at(c, KOFF); };
+        auto ldv = [&](int p, int h) -> u32x2 { return ldv_at(p, h, VOFF); };
         // softmax state of this iteration
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, tmax = 0.f, nms = 0.f, alpha = 1.f;
         f32x2 sum2 = {0.f, 0.f};
@@ -385,11 +383,11 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         // first fragments of iteration i+1 (its blocks are already visible, see the header)
         if constexpr (NQK) {
 #pragma unroll
-            for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, nko_rt + NKOFF);
+            for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, NKOFF);
         }
         if constexpr (NPVF) {
 #pragma unroll
-            for (int p = 0; p < PDV; ++p) { vfr[p][0] = ldv_at(p, 0, nvo_rt + NVOFF); vfr[p][1] = ldv_at(p, 1, nvo_rt + NVOFF); }
+            for (int p = 0; p < PDV; ++p) { vfr[p][0] = ldv_at(p, 0, NVOFF); vfr[p][1] = ldv_at(p, 1, NVOFF); }
         }
         if constexpr (SM && !(ABL & 4)) {
             l_run = l_run * alpha + (sum2[0] + sum2[1]);
@@ -441,7 +439,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         const int ii = i0 + (R);                                                                             \
         iter(HYD_IC(slot_k((R) & 3)), HYD_IC(slot_v(((R) + 2) & 3)), HYD_IC(slot_k(((R) + 1) & 3)),          \
              HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(7 + 8 + 16 + 32), HYD_IC(1), SW, SR, PW, PR, kw_of(ii),   \
-             ii >= 0 && ii < NB, 0, 0, 0, 0, rsrc_of(kbase, a.k_ts, ii + 4), rsrc_of(vbase, a.v_ts, ii + 2), \
+             ii >= 0 && ii < NB, rsrc_of(kbase, a.k_ts, ii + 4), rsrc_of(vbase, a.v_ts, ii + 2), \
              slot_k(((R) + 3) & 3), slot_v(((R) + 1) & 3));                                                  \
         dma_wait<2 * NLB>();                                                                                 \
         if (!(ABL & 16)) __syncthreads();                                                                    \
