@@ -38,12 +38,13 @@ def rdiff(a, b, eps=1e-8):
     return 2 * np.abs(a - b) / (np.abs(a) + np.abs(b) + eps)
 
 
-def assert_close(got, want, dtype, what=""):
+def assert_close(got, want, dtype, what="", rtol_mean=None):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     assert np.isfinite(got).all(), f"{what}: non-finite output"
     err = np.abs(got - want).max()
     mrd = rdiff(got, want).mean()
-    assert err <= ATOL[dtype] and mrd <= RTOL_MEAN[dtype], f"{what}: max abs {err:.3e} mean rdiff {mrd:.3e}"
+    rt = RTOL_MEAN[dtype] if rtol_mean is None else rtol_mean
+    assert err <= ATOL[dtype] and mrd <= rt, f"{what}: max abs {err:.3e} mean rdiff {mrd:.3e}"
     return err, mrd
