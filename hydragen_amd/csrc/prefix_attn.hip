@@ -148,8 +148,6 @@ __global__ __launch_bounds__(512) void prefix_attn_kernel(const PrefixArgs a) {
     constexpr int KH_BYTES = 64 * RB;
     constexpr int V_BYTES = 128 * RB;
     constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = 4 * KH_BYTES;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     typedef const __attribute__((address_space(3))) char* lptr_c;
 
     // ---- per-lane LDS byte addresses; tile/buffer/row-block offsets are compile-time immediates -------
