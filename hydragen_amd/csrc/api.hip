@@ -27,7 +27,7 @@ constexpr int kMaxSplits = 32;
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct PrefixPlan {
-    int g, per, row_blocks, nsplit, split_len, grid, qpg;
+    int g, per, row_blocks, nsplit, split_len, grid, qpg, wg_rows;
 };
 
 int check_common(int dtype, int B, int nq, int Hq, int Hkv, int D) {
@@ -59,6 +59,25 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
     pl->qpg = qtok_per_group;
     const int64_t mrows = (int64_t)qtok_per_group * pl->g;
     pl->row_blocks = (int)((mrows + 127) / 128);
+    pl->wg_rows = 128;
+    {
+        // 256-row workgroups (pipelined kernel, D = 128) when 128-row ones would need two or more rounds of the chip
+        // anyway: half the K/V staging per flop and no cross-half merge.  HYD_PREFIX_ROWS=128|256 forces either (A/B).
+        static const int force_rows = [] {
+            const char* e = getenv("HYD_PREFIX_ROWS");
+            return e ? atoi(e) : 0;
+        }();
+        static const bool w8 = [] {
+            const char* e = getenv("HYD_PREFIX_IMPL");
+            return e && !strcmp(e, "w8");
+        }();
+        const int64_t units128 = (int64_t)p->sb * p->Hkv * pl->row_blocks;
+        const bool can = p->D == 128 && !w8;
+        if (can && (force_rows == 256 || (force_rows == 0 && units128 >= 2 * kNumCU))) {
+            pl->wg_rows = 256;
+            pl->row_blocks = (int)((mrows + 255) / 256);
+        }
+    }
     const int64_t units = (int64_t)p->sb * p->Hkv * pl->row_blocks;
     int ns = p->num_splits;
     if (ns <= 0) {
@@ -114,6 +133,7 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->per = pl.per;
     a->kv_len = p->kv_len;
     a->row_blocks = pl.row_blocks;
+    a->wg_rows = pl.wg_rows;
     a->nsplit = pl.nsplit;
     a->split_len = pl.split_len;
     a->lse_q_stride = pl.qpg;

@@ -65,16 +65,21 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" 
 
 // ABL: development-only timing ablations (bit0 no in-loop DMA, bit1 no exp groups, bit2 no softmax VALU at all,
 // bit3 no LDS fragment reads, bit4 no barrier in the fast loop); only ABL = 0 is ever used for results.
-template <typename T, int D, bool CAUSAL, int ABL = 0>
+// KG: key groups per 128-key tile.  KG = 2 (default): 128 rows per workgroup, wave = (row block, key half).  KG = 1: 256
+// rows per workgroup, every wave walks all keys 32 at a time -- half the K/V staging per flop and no cross-half merge,
+// for shapes with enough rows per kv head to fill the chip with 256-row workgroups (D = 128 only).
+template <typename T, int D, bool CAUSAL, int ABL = 0, int KG = 2>
 __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a) {
     using TR = Traits<T>;
     constexpr int RB = D * 2;            // bytes per K/V row
     constexpr int NC = D / 16;           // k-chunks of the QK^T contraction
     constexpr int NDB = D / 32;          // 32-wide d blocks of O^T
-    constexpr int NLB = RB / 128;        // DMA instructions per wave per 32-key block per tensor
+    constexpr int NLB = KG == 2 ? RB / 128 : 1;  // DMA instructions per wave per 32-key block per tensor
+    static_assert(KG == 2 || D == 128, "KG = 1 is instantiated for D = 128 only (one DMA instruction per wave and block)");
+    constexpr int RWG = KG == 2 ? 128 : 256;  // query rows per workgroup
     constexpr int RPI = 1024 / RB;       // rows per DMA instruction
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* mlbuf = reinterpret_cast<float*>(smem + 512 * RB);  // [8 waves][2][64], after the K/V rings
+    float* mlbuf = reinterpret_cast<float*>(smem + (KG == 2 ? 512 : 256) * RB);  // [8 waves][2][64], after the K/V rings
 
     unsigned tst[6] = {0, 0, 0, 0, 0, 0};
     auto stampk = [&](int k) __attribute__((always_inline)) {
@@ -88,8 +93,8 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave >> 2;  // key half of every 128-key tile this wave computes on
-    const int rw = wave & 3;   // 32-row sub-block
+    const int kg = KG == 2 ? wave >> 2 : 0;  // key half of every 128-key tile this wave computes on
+    const int rw = KG == 2 ? wave & 3 : wave;  // 32-row sub-block
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- which (group, kv head, split, row block) ------------------------------------------
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         nq_eff = a.nq;
     }
     const int Mrows = nqtok * a.g;
-    if (rb * 128 >= Mrows) return;  // block-uniform
+    if (rb * RWG >= Mrows) return;  // block-uniform
 
     const uint16_t* k16 = static_cast<const uint16_t*>(a.k);
     const uint16_t* v16 = static_cast<const uint16_t*>(a.v);
@@ -134,15 +139,16 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     int kend = min(L, kbeg + a.split_len);
     if (CAUSAL && a.per == 1) {
         // rows of this block only see keys <= iq_max + L - nq
-        const int rmax = min(Mrows, rb * 128 + 128) - 1;
+        const int rmax = min(Mrows, rb * RWG + RWG) - 1;
         kend = min(kend, rmax / a.g + L - nq_eff + 1);
     }
     const int nkeys = kend > kbeg ? kend - kbeg : 0;
     const int nkt = (nkeys + 127) >> 7;
-    const int NB = 2 * nkt;  // 32-key blocks per wave (its half of every tile)
+    // 32-key blocks per wave: its half of every tile (KG = 2) or all keys (KG = 1); even, the loop runs in pairs
+    const int NB = KG == 2 ? 2 * nkt : 2 * ((nkeys + 63) >> 6);
 
     // ---- this lane's query row ------------------------------------------------------------
-    const int r = rb * 128 + rw * 32 + l31;
+    const int r = rb * RWG + rw * 32 + l31;
     const bool rvalid = r < Mrows;
     const int rtok = rvalid ? r / a.g : 0;  // query token inside the group
     const int hq = hk * a.g + (rvalid ? r % a.g : 0);
@@ -163,12 +169,13 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     // ---- LDS map (bytes): KA[2 tiles] | KB[2 tiles] | V[2 tiles] | mlbuf ------------------------------
     // KA: rows 0..63 of a K tile (kg = 0 waves), KB: rows 64..127 (kg = 1 waves), V: 128 rows.
     // Ring slot s (block b, s = b & 3): tile buffer s >> 1, rows [(s & 1) * 32, +32) of each 64-row half.
+    // KG = 1: K[4 slots of 32 rows] | V[4 slots of 32 rows] | mlbuf.
     constexpr int KH_BYTES = 64 * RB;
-    constexpr int V_BYTES = 128 * RB;
-    constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = 4 * KH_BYTES;
+    constexpr int V_BYTES = KG == 2 ? 128 * RB : 64 * RB;  // two ring slots of V
+    constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = KG == 2 ? 4 * KH_BYTES : 2 * KH_BYTES;
     typedef const __attribute__((address_space(3))) char* lptr_c;
-    auto slot_k = [](int s) { return (s >> 1) * KH_BYTES + (s & 1) * 32 * RB; };
-    auto slot_v = [](int s) { return (s >> 1) * V_BYTES + (s & 1) * 32 * RB; };
+    auto slot_k = [](int s) { return KG == 2 ? (s >> 1) * KH_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
+    auto slot_v = [](int s) { return KG == 2 ? (s >> 1) * V_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
 
     // ---- per-lane LDS byte addresses of the MFMA fragments (ring slot 0) -------------------------------
     const int ksw = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
@@ -198,14 +205,14 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
         const int q = wave * NLB + i;
-        const int rr = q * RPI + drow, h = rr >> 5, r32 = rr & 31;
+        const int rr = q * RPI + drow, h = KG == 2 ? rr >> 5 : 0, r32 = rr & 31;
         const int kch = D == 128 ? (dcp ^ (r32 & 15)) : (dcp ^ ((r32 >> 1) & 7));
         const int vs_ = D == 128 ? (r32 & 3) : ((r32 >> 1) & 1);
         const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
         drr[i] = h * 64 + r32;
         koffb[i] = (unsigned)(((int64_t)drr[i] * a.k_ts + kch * 8) * 2);
         voffb[i] = (unsigned)(((int64_t)drr[i] * a.v_ts + vch * 8) * 2);
-        const int qh = (q * RPI) >> 5, qr = (q * RPI) & 31;  // wave-uniform
+        const int qh = KG == 2 ? (q * RPI) >> 5 : 0, qr = (q * RPI) & 31;  // wave-uniform
         kdst[i] = __builtin_amdgcn_readfirstlane(lds0 + (qh ? KB_OFF : KA_OFF) + qr * RB);
         vdst[i] = __builtin_amdgcn_readfirstlane(lds0 + V_OFF + (qh * 64 + qr) * RB);
     }
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     // DMA of 32-key block b (any integer: blocks / rows outside [0, nkeys) become zeros in LDS) into ring
     // slot b & 3; piece = one of the 2 * NLB instructions of the (K block, V block) pair of an iteration.
     auto rsrc_of = [&](const char* base, int64_t ts, int b) -> u32x4 {
-        const int row0 = (b >> 1) * 128 + (b & 1) * 32;
-        const int rem = min(nkeys - row0, 128);  // rows the 96-row window of this block pair may touch
+        const int row0 = KG == 2 ? (b >> 1) * 128 + (b & 1) * 32 : b * 32;
+        const int rem = min(nkeys - row0, KG == 2 ? 128 : 32);  // rows the window of this block (pair) may touch
         const unsigned bytes = (b >= 0 && rem > 0) ? (unsigned)((int64_t)(rem - 1) * ts * 2 + RB) : 0u;
         return make_rsrc(base + (int64_t)(b >= 0 ? row0 : 0) * ts * 2, bytes);
     };
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     using std::integral_constant;
 #define HYD_IC(x) integral_constant<int, (x)>{}
     const int kwave = kbeg + kg * 64;  // first key of this wave's half of tile 0
-    auto kw_of = [&](int b) { return kwave + (b >> 1) * 128 + (b & 1) * 32; };
+    auto kw_of = [&](int b) { return KG == 2 ? kwave + (b >> 1) * 128 + (b & 1) * 32 : kwave + b * 32; };
     // Every iteration i = -1 .. NB runs the same code: stages whose block does not exist work on zeros /
     // fully masked scores (QK(NB) and SM(-1), SM(NB) are harmless, PV(-2), PV(-1) add P = 0 times finite V).
     // Cold start: every workgroup of the chip fetches at once, so only what the first iteration needs is waited
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
         dma_block(0, false);
         dma_block(1, false);
         // slots 2 and 3 of the V ring (= tile buffer 1) are read by PV(-2) / PV(-1) with P = 0: must hold finite data
-        for (int off = tid * 16; off < V_BYTES; off += 512 * 16)
+        for (int off = tid * 16; off < V_BYTES; off += 512 * 16)  // V_BYTES = two slots in either layout
             *reinterpret_cast<u32x4*>(smem + V_OFF + V_BYTES + off) = u32x4{0u, 0u, 0u, 0u};
     }
     // Make the compiler wait for the Q fragments here, not (conservatively, with vmcnt(0)) inside the loop.
@@ -464,11 +471,10 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     // 4 consecutive d per (d block, q4); v_permlane32_swap pairs the two half-waves' groups so that each lane
     // stores 16 contiguous bytes (row-per-lane stores are issue-bound: 4 instead of 16 per wave, on all 8 waves).
     stampk(3);
-    constexpr int HDB = NDB / 2;
+    constexpr int HDB = KG == 2 ? NDB / 2 : NDB;  // d blocks this wave finalises
     const float l_tot = pair_sum(l_run);
     f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [8 waves][HDB * 4][64 lanes] of f32x4
-    {
-        const int dbo = kg ? 0 : HDB;  // first d block handed over
+    if constexpr (KG == 2) {
 #pragma unroll
         for (int i = 0; i < HDB; ++i)
 #pragma unroll
@@ -477,15 +483,14 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
                 f32x4 x = {ob[4 * q4], ob[4 * q4 + 1], ob[4 * q4 + 2], ob[4 * q4 + 3]};
                 obuf[(wave * HDB * 4 + i * 4 + q4) * 64 + lane] = x;
             }
-        (void)dbo;
         mlbuf[wave * 128 + lane] = m_run;
         mlbuf[wave * 128 + 64 + lane] = l_tot;
     }
-    __syncthreads();
+    if constexpr (KG == 2) __syncthreads();
     stampk(4);
     const int pw = wave ^ 4;  // partner wave
-    const float m1 = mlbuf[pw * 128 + lane];
-    const float l1 = mlbuf[pw * 128 + 64 + lane];
+    const float m1 = KG == 2 ? mlbuf[pw * 128 + lane] : -INFINITY;
+    const float l1 = KG == 2 ? mlbuf[pw * 128 + 64 + lane] : 0.f;
     const float mf = fmaxf(m_run, m1);
     const float mfs = (mf == -INFINITY) ? 0.f : mf;
     const float a0 = fast_exp2(m_run - mfs), a1 = fast_exp2(m1 - mfs);
@@ -496,14 +501,19 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     const int64_t obase = (int64_t)sp * a.out_split_stride + row_off;
 #pragma unroll
     for (int i = 0; i < HDB; ++i) {
-        const f32x16& ob = kg ? o[HDB + i] : o[i];
-        const int db = kg * HDB + i;
+        const f32x16& ob = (KG == 2 && kg) ? o[NDB - HDB + i] : o[i];
+        const int db = KG == 2 ? kg * HDB + i : i;
         f32x4 x[4];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 y = obuf[(pw * HDB * 4 + i * 4 + q4) * 64 + lane];
+            if constexpr (KG == 2) {
+                const f32x4 y = obuf[(pw * HDB * 4 + i * 4 + q4) * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[q4][j] = ob[4 * q4 + j] * w0 + y[j] * w1;
+                for (int j = 0; j < 4; ++j) x[q4][j] = ob[4 * q4 + j] * w0 + y[j] * w1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[q4][j] = ob[4 * q4 + j] * w0;
+            }
         }
         if (a.out_f32) {
             if (rvalid) {
@@ -549,10 +559,10 @@ __global__ __launch_bounds__(512) void prefix_attn_pl_kernel(const PrefixArgs a)
     }
 }
 
-template <typename T, int D, bool CAUSAL, int ABL = 0>
+template <typename T, int D, bool CAUSAL, int ABL = 0, int KG = 2>
 static int launch_prefix_pl_t(const PrefixArgs& a, int grid, hipStream_t s) {
-    constexpr size_t lds = 2 * 256 * (D * 2) + 8 * 128 * sizeof(float);
-    auto kern = prefix_attn_pl_kernel<T, D, CAUSAL, ABL>;
+    constexpr size_t lds = (KG == 2 ? 2 : 1) * 256 * (D * 2) + 8 * 128 * sizeof(float);
+    auto kern = prefix_attn_pl_kernel<T, D, CAUSAL, ABL, KG>;
     static bool attr_set = false;  // idempotent; value never changes
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -574,6 +584,12 @@ int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int gri
         }
     }
 #endif
+    if (a.wg_rows == 256) {
+        if (D != 128) return (int)hipErrorInvalidValue;
+        if (dtype == HYD_F16)
+            return causal ? launch_prefix_pl_t<F16, 128, true, 0, 1>(a, grid, s) : launch_prefix_pl_t<F16, 128, false, 0, 1>(a, grid, s);
+        return causal ? launch_prefix_pl_t<BF16, 128, true, 0, 1>(a, grid, s) : launch_prefix_pl_t<BF16, 128, false, 0, 1>(a, grid, s);
+    }
 #define HYD_DISPATCH(TT, DD)                                                    \
     return causal ? launch_prefix_pl_t<TT, DD, true>(a, grid, s) : launch_prefix_pl_t<TT, DD, false>(a, grid, s)
     if (dtype == HYD_F16) {
