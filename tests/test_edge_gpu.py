@@ -175,3 +175,21 @@ def test_repeated_launches_are_bit_identical():
         torch.cuda.synchronize()
         for o in outs[1:]:
             assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16)), (B, P, S, Hq, Hkv)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("sk", [70, 300])
+def test_prefix_256_row_workgroups(dt, sk):
+    """Enough query rows (8 kv heads x 8229 rows = 520 128-row blocks >= 2 rounds of the chip) for the planner to pick
+    the 256-row instantiation of the prefix kernel; the last workgroup of every head is ragged (8229 = 32 * 256 + 37)."""
+    from hydragen_amd import _lib
+    from hydragen_amd.flash import flash_attention
+
+    rng = np.random.default_rng(41 + sk)
+    q = _rand(rng, (1, 8229, 8, 128), dt)
+    k, v = _rand(rng, (1, sk, 8, 128), dt), _rand(rng, (1, sk, 8, 128), dt)
+    out, lse = flash_attention(dev(q, dt), dev(k, dt), dev(v, dt))
+    torch.cuda.synchronize()
+    want, wlse = O.flash_attention(q, k, v)
+    assert_close(out.float().cpu().numpy(), want, dt, "256-row workgroups: out")
+    assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3
