@@ -61,7 +61,7 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
     pl->row_blocks = (int)((mrows + 127) / 128);
     pl->wg_rows = 128;
     {
-        // 256-row workgroups (pipelined kernel, D = 128) when 128-row ones would need two or more rounds of the chip
+        // 256-row workgroups (pipelined kernel, D = 128) when 128-row ones would need more than one round of the chip
         // anyway: half the K/V staging per flop and no cross-half merge.  HYD_PREFIX_ROWS=128|256 forces either (A/B).
         static const int force_rows = [] {
             const char* e = getenv("HYD_PREFIX_ROWS");
@@ -73,7 +73,7 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
         }();
         const int64_t units128 = (int64_t)p->sb * p->Hkv * pl->row_blocks;
         const bool can = p->D == 128 && !w8;
-        if (can && (force_rows == 256 || (force_rows == 0 && units128 >= 2 * kNumCU))) {
+        if (can && (force_rows == 256 || (force_rows == 0 && units128 > kNumCU))) {
             pl->wg_rows = 256;
             pl->row_blocks = (int)((mrows + 255) / 256);
         }
