@@ -48,3 +48,22 @@ def assert_close(got, want, dtype, what="", rtol_mean=None):
     rt = RTOL_MEAN[dtype] if rtol_mean is None else rtol_mean
     assert err <= ATOL[dtype] and mrd <= rt, f"{what}: max abs {err:.3e} mean rdiff {mrd:.3e}"
     return err, mrd
+
+
+REL_L2 = {"f16": 1e-3, "bf16": 8e-3}
+
+
+def assert_close_l2(got, want, dtype, what=""):
+    """Maximum absolute error (the reference's atol, x 2^3 for bf16) and relative L2 error ||got - want|| / ||want||
+    <= 1e-3 for fp16 (the figure BASELINE.json states), x 2^3 for bf16.  Used where tensors are small: the
+    reference's third figure, the MEAN element-wise relative difference (tests/test_attention.py:183-185), is kept
+    for the reference-shaped cases but is dominated by outputs near zero on tensors of a few hundred elements (a
+    5000-seed soak, tools/soak.py: relative L2 peaks at 4.0e-4 / 3.3e-3 while the mean relative difference of the
+    same runs scatters up to 1.6e-2 on fp16 cases whose largest absolute error is 5e-5)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape and np.isfinite(got).all(), what
+    err = np.abs(got - want).max()
+    l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+    assert err <= ATOL[dtype] and l2 <= REL_L2[dtype], f"{what}: max abs {err:.3e} relative L2 {l2:.3e}"
+    return err, l2
