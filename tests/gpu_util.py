@@ -54,7 +54,8 @@ REL_L2 = {"f16": 1e-3, "bf16": 8e-3}
 
 
 def assert_close_l2(got, want, dtype, what=""):
-    """Maximum absolute error (the reference's atol, x 2^3 for bf16) and relative L2 error ||got - want|| / ||want||
+    """Maximum absolute error (the reference's atol, x 2^3 for bf16, scaled by max |want| when outputs exceed 1: the
+    bound is ~2 ulp of the storage dtype at magnitude 1) and relative L2 error ||got - want|| / ||want||
     <= 1e-3 for fp16 (the figure BASELINE.json states), x 2^3 for bf16.  Used where tensors are small: the
     reference's third figure, the MEAN element-wise relative difference (tests/test_attention.py:183-185), is kept
     for the reference-shaped cases but is dominated by outputs near zero on tensors of a few hundred elements (a
@@ -65,5 +66,6 @@ def assert_close_l2(got, want, dtype, what=""):
     assert got.shape == want.shape and np.isfinite(got).all(), what
     err = np.abs(got - want).max()
     l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
-    assert err <= ATOL[dtype] and l2 <= REL_L2[dtype], f"{what}: max abs {err:.3e} relative L2 {l2:.3e}"
+    atol = ATOL[dtype] * max(1.0, float(np.abs(want).max()))
+    assert err <= atol and l2 <= REL_L2[dtype], f"{what}: max abs {err:.3e} (bound {atol:.3e}) relative L2 {l2:.3e}"
     return err, l2
