@@ -6,24 +6,33 @@ bench.py -- decode attention hot path (Hydragen decomposed shared-prefix attenti
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): bf16, batch 1024, one shared prefix of 2048 tokens,
-Llama-2-7B head config (32 q heads = 32 kv heads, head_dim 128), unique suffix growing
-1 -> 128 tokens.  One "step" = ONE pass of the hot path for one decode token of one layer:
-`hydragen_attention` (prefix pass + suffix pass + fused LSE combine) over the whole batch with
-suffix length s = 1 + (step mod 128).  value = batch * steps / wall time (tokens/s through the
-attention layer), all inputs resident in HBM before the timed region.
+Workload (BASELINE.json configs[1], "C2"): bf16, batch 1024, one shared prefix of 2048 tokens, Llama-2-7B head
+config (32 q heads = 32 kv heads, head_dim 128), unique suffix anywhere in 1..128 tokens.
 
-N > 1: tensor-parallel head sharding exactly as /root/reference/hydragen/tp.py:90-124
-(Hq/N query heads and Hkv/N kv heads per rank, batch replicated) with the per-layer
-all-reduce(sum) of the [B, 1, hidden] attention block output (tp.py:108-112) on RCCL.
-Total work is fixed -> "strong" scaling.
+One "step" = ONE pass of the hot path for one decode token of one layer at ONE fixed suffix length s:
+`hydragen_attention` (prefix pass + suffix pass + fused LSE combine) over the whole batch.  The K timed steps
+sample s uniformly over 1..128 whatever K is (`suffix_schedule`: s_i = 1 + floor(frac((i + 1/2) * c / K) * 128),
+c = ceil(K / 128)), so the mean suffix is 64.5 for K = 20 as for K = 256; the lengths actually run are printed in
+`config`.  value = batch * steps / wall time (tokens/s through the attention layer), all inputs resident in HBM
+before the timed region.  Each step issues the product's `hyd_decode_attn_fused` as its two documented phases
+(HYD_PHASE_SHARED, HYD_PHASE_UNIQUE: the same two kernel launches as the one-call form) with a HIP event between
+them, so each kernel's duration is measured inside the timed region on the launch stream.
 
-Extra objects on the JSON line:
-  roofline       dominant kernel (suffix pass, HBM-bound): algorithmic bytes / HIP-event time
-  roofline_prefix  prefix-pass MFMA utilisation (4*B*Hq*P*D flops / HIP-event time / 2.5 PF/s)
-  nosharing      the no-sharing FlashAttention-equivalent baseline on the same GPU (every sequence
-                 owns a private [P+S] KV; same suffix kernel) and the speedup over it
-  cpu_baseline   oracle/cpu_port_torch.py (a port: the reference has no CPU path) on the host cores
+N > 1: tensor-parallel head sharding exactly as /root/reference/hydragen/tp.py:90-124 (Hq/N query heads and
+Hkv/N kv heads per rank, batch replicated) with the per-layer all-reduce(sum) of the [B, 1, hidden] attention
+block output (tp.py:108-112) on RCCL, timed with its own events.  Total work is fixed -> "strong" scaling.
+
+Extra objects on the JSON line (rank 0):
+  roofline            the kernel that took most of the timed region (by its events): algorithmic bytes or flops /
+                      mean launch duration against the gfx950 peak; the other kernel in `roofline_other`
+  reference_protocol  the reference's own timing protocol (hydragen/benchmark_utils.py:82-170,
+                      scripts/microbenchmark.py:24-47): operator captured in a HIP graph, replays timed one by one
+                      with a 512 MB cache flush in between, mean / std / rstd per sweep point s = 16..128
+                      (docs/sweeps_from_paper.md:159-161), next to the no-sharing baseline under the same protocol
+  accuracy            measured bf16 error of the operator at this shape against fp64 attention over [prefix; suffix]
+  model_decode        decode tokens/s of a random-weight Llama-2-7B through HydragenLlamaForCausalLM.generate
+                      (scripts/synth.py:33-79,207-226 protocol), N = 1 only
+  cpu_baseline        oracle/cpu_port_torch.py (a port: the reference has no CPU path) on the host cores
 """
 
 from __future__ import annotations
@@ -31,8 +40,10 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -45,6 +56,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
+SWEEP = (16, 32, 48, 64, 80, 96, 112, 128)  # docs/sweeps_from_paper.md:159-161 restricted to C2's 0..128
 
 
 def parse():
@@ -60,19 +72,35 @@ def parse():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nosharing", action="store_true")
+    ap.add_argument("--no-protocol", action="store_true", help="skip the graph + flush reference-protocol sweep")
+    ap.add_argument("--no-model", action="store_true", help="skip the Llama-2-7B decode tokens/s leg")
+    ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--model-new-tokens", type=int, default=128)
+    ap.add_argument("--no-graph-collective", action="store_true",
+                    help="N > 1: skip the HIP-graph capture of (attention + all-reduce), llama.py:849-854")
     return ap.parse_args()
 
 
-class Ops:
-    """One decode step = ONE call of the product's fused entry point (`hyd_decode_attn_fused`, what
-    hydragen_amd.attention.hydragen_attention issues), through its measurement twin
-    `hyd_decode_attn_fused_timed`, which records a HIP event between the prefix pass and the suffix pass
-    so that each kernel can be timed inside the timed region."""
+def suffix_schedule(steps: int, smax: int) -> list[int]:
+    """Suffix length of every timed step: a uniform cover of 1..smax for ANY step count (>= 8 to be meaningful)."""
+    c = max(1, math.ceil(steps / smax))
+    return [1 + int((((i + 0.5) * c / steps) % 1.0) * smax) for i in range(steps)]
 
-    def __init__(self, q, k, v, sk, sv):
+
+def describe_schedule(sched: list[int]) -> str:
+    if len(sched) <= 32:
+        return ",".join(map(str, sched))
+    return f"{len(sched)} steps, min {min(sched)}, max {max(sched)}, mean {sum(sched) / len(sched):.2f} (uniform cover)"
+
+
+class Ops:
+    """Pre-marshalled `hyd_decode_params` per suffix length (one per phase), so a step costs two ctypes calls."""
+
+    def __init__(self, q, k, v, sk, sv, lens_needed):
         from hydragen_amd import _lib
-        from hydragen_amd._lib import DecodeParams
+        from hydragen_amd._lib import DecodeParams, HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE
         from hydragen_amd.attention import _fill_level
         from hydragen_amd.flash import fill_suffix_params
 
@@ -82,21 +110,32 @@ class Ops:
         self.out = torch.empty_like(q)
         self.params, self.keep = {}, []
         ws_bytes = 0
-        for s in range(1, k.shape[1] + 1):
+        for s in sorted(set(lens_needed)):
             sl = torch.full((B,), s, dtype=torch.int32, device=q.device)
-            p = DecodeParams()
-            fill_suffix_params(p.suffix, q, k, v, sl, self.out)
-            p.n_levels = 1
-            _fill_level(p.levels[0], sk, sv, None, None, False, B)
-            ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(p)))
-            self.params[s] = p
+            trio = []
+            for phase in (HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE):
+                p = DecodeParams()
+                fill_suffix_params(p.suffix, q, k, v, sl, self.out)
+                p.n_levels = 1
+                p.phase = phase
+                _fill_level(p.levels[0], sk, sv, None, None, False, B)
+                trio.append(p)
+            ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(trio[0])))
+            self.params[s] = trio
             self.keep.append(sl)
         self.ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
-        for p in self.params.values():
-            p.workspace, p.workspace_bytes = self.ws.data_ptr(), ws_bytes
+        for trio in self.params.values():
+            for p in trio:
+                p.workspace, p.workspace_bytes = self.ws.data_ptr(), ws_bytes
 
-    def step(self, s, stream, ev_mid=None):
-        self._lib.check(self.lib.hyd_decode_attn_fused_timed(C.byref(self.params[s]), stream, ev_mid))
+    def fused(self, s, stream):
+        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][0]), stream))
+
+    def shared_phase(self, s, stream):
+        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][1]), stream))
+
+    def unique_phase(self, s, stream):
+        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][2]), stream))
 
 
 def main():
@@ -130,43 +169,53 @@ def main():
     v = torch.randn(B, S, Hkv, D, device=dev, dtype=dt)
     sk = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
     sv = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
-    ops = Ops(q, k, v, sk, sv)
+    sched = suffix_schedule(args.steps, S)
+    warm_sched = suffix_schedule(max(args.warmup, 1), S)
+    sweep = [s for s in SWEEP if s <= S]
+    ops = Ops(q, k, v, sk, sv, sched + warm_sched + sweep)
     # stand-in for the row-parallel o_proj partial output that tp.py:108-112 all-reduces
     ar_buf = torch.randn(B, 1, hidden, device=dev, dtype=dt) if world > 1 else None
+    ar_host = ar_buf.float().cpu() if (world > 1 and backend != "nccl") else None
     stream = torch.cuda.current_stream().cuda_stream
 
-    def suffix_len(i):
-        return 1 + (i % S)
+    def collective():
+        if backend == "nccl":
+            dist.all_reduce(ar_buf)
+        else:  # gloo self-test: reduce a host copy
+            dist.all_reduce(ar_host)
 
-    def step(i, ev=None):
-        s = suffix_len(i)
-        if ev is not None:
-            ev[0].record()
-            ops.step(s, stream, ev[1].cuda_event)
-            ev[2].record()
-        else:
-            ops.step(s, stream)
+    def step(s, ev=None):
+        if ev is None:
+            ops.shared_phase(s, stream)
+            ops.unique_phase(s, stream)
+            if world > 1:
+                collective()
+            return
+        ev[0].record()
+        ops.shared_phase(s, stream)
+        ev[1].record()
+        ops.unique_phase(s, stream)
+        ev[2].record()
         if world > 1:
-            if backend == "nccl":
-                dist.all_reduce(ar_buf)
-            else:  # gloo self-test: reduce a host copy
-                dist.all_reduce(ar_host)
+            collective()
+            ev[3].record()
 
-    ar_host = ar_buf.float().cpu() if (world > 1 and backend != "nccl") else None
     for i in range(args.warmup):
-        step(i)
+        step(warm_sched[i])
     torch.cuda.synchronize()
 
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    nev = 4 if world > 1 else 3
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(args.steps)]
     for ev in events:  # materialise the hipEvent_t handles (torch creates them lazily)
-        ev[1].record()
+        for e_ in ev:
+            e_.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, events[i])
+        step(sched[i], events[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,10 +230,37 @@ def main():
     e = 2
     pre_ms = [ev[0].elapsed_time(ev[1]) for ev in events]
     suf_ms = [ev[1].elapsed_time(ev[2]) for ev in events]
-    suf_bytes = [2 * e * Hkv * D * B * suffix_len(i) + 2 * B * Hq * D * e + 4 * B * Hq for i in range(args.steps)]
+    suf_bytes = [2 * e * Hkv * D * B * s + 2 * B * Hq * D * e + 4 * B * Hq for s in sched]
     pre_flops = 4.0 * B * Hq * P * D
     suf_gbs = sum(suf_bytes) / (sum(suf_ms) * 1e-3) / 1e9
     pre_tflops = pre_flops * args.steps / (sum(pre_ms) * 1e-3) / 1e12
+    suffix_roof = {
+        "kernel": "suffix_attn_kernel (suffix pass + fused LSE combine)",
+        "bound": "hbm", "achieved": suf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": suf_gbs / HBM_PEAK_GBS, "traffic": None,
+        "avg_launch_us": sum(suf_ms) / args.steps * 1e3,
+        "algorithmic_bytes_per_launch_mean": sum(suf_bytes) / args.steps,
+        "share_of_timed_region": sum(suf_ms) / (sum(suf_ms) + sum(pre_ms)),
+    }
+    prefix_roof = {
+        "kernel": "prefix_attn kernel (batched-query MFMA pass over the shared prefix)",
+        "bound": "mfma", "achieved": pre_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": pre_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+        "avg_launch_us": sum(pre_ms) / args.steps * 1e3,
+        "flops_per_launch": pre_flops,
+        "share_of_timed_region": sum(pre_ms) / (sum(suf_ms) + sum(pre_ms)),
+    }
+    _attach_traffic(suffix_roof, prefix_roof, args, world)
+    dominant_is_suffix = sum(suf_ms) >= sum(pre_ms)
+
+    # achieved fraction per suffix bucket (the fixed cost of the suffix pass shows at small s)
+    buckets = {}
+    for lo, hi in ((1, 16), (17, 32), (33, 64), (65, 96), (97, 128)):
+        idx = [i for i, s in enumerate(sched) if lo <= s <= hi]
+        if idx:
+            g = sum(suf_bytes[i] for i in idx) / (sum(suf_ms[i] for i in idx) * 1e-3) / 1e9
+            buckets[f"{lo}-{hi}"] = {"steps": len(idx), "GB/s": g, "frac": g / HBM_PEAK_GBS,
+                                     "suffix_us": sum(suf_ms[i] for i in idx) / len(idx) * 1e3}
 
     res = {
         "metric": "decode_attention_tokens_per_sec",
@@ -200,82 +276,255 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"C2 decode attention layer-step: batch {B}, shared prefix {P}, suffix 1..{S} (cyclic), "
-                        f"{args.qheads}q/{args.kvheads}kv heads d={D}, one hydragen_attention call per step",
-            "batch": B, "prefix_len": P, "suffix_len": f"1..{S}", "qheads": args.qheads, "kvheads": args.kvheads,
-            "head_dim": D, "parallelism": f"tp{world} (heads sharded, all-reduce [B,1,{hidden}] bf16 per step)" if world > 1 else "single GPU",
+            "workload": f"C2 decode attention layer-step: batch {B}, shared prefix {P}, {args.qheads}q/{args.kvheads}kv heads "
+                        f"d={D}, one hydragen_attention call per step at a fixed suffix length; suffix lengths of the timed "
+                        f"steps: {describe_schedule(sched)}",
+            "batch": B, "prefix_len": P, "suffix_lens": sched if len(sched) <= 64 else describe_schedule(sched),
+            "suffix_len_mean": sum(sched) / len(sched), "qheads": args.qheads, "kvheads": args.kvheads, "head_dim": D,
+            "parallelism": f"tp{world} (heads sharded, all-reduce [B,1,{hidden}] bf16 per step)" if world > 1 else "single GPU",
         },
         "attn_us_per_step": elapsed / args.steps * 1e6,
         "prefix_us": sum(pre_ms) / args.steps * 1e3,
         "suffix_us_mean": sum(suf_ms) / args.steps * 1e3,
-        "roofline": {
-            "kernel": "suffix_attn_kernel (suffix pass + fused LSE combine)",
-            "bound": "hbm", "achieved": suf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": suf_gbs / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_launch_mean": sum(suf_bytes) / args.steps,
-        },
-        "roofline_prefix": {
-            "kernel": "prefix_attn_pl_kernel (batched-query MFMA pass, software-pipelined)",
-            "bound": "mfma", "achieved": pre_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": pre_tflops / MFMA_PEAK_TFLOPS, "flops_per_launch": pre_flops,
-        },
+        "suffix_frac_by_suffix_len": buckets,
+        "roofline": suffix_roof if dominant_is_suffix else prefix_roof,
+        "roofline_other": prefix_roof if dominant_is_suffix else suffix_roof,
     }
+    if world > 1:
+        ar_ms = [ev[2].elapsed_time(ev[3]) for ev in events]
+        res["allreduce_us"] = sum(ar_ms) / args.steps * 1e3
+        res["allreduce_bytes"] = ar_buf.numel() * 2
+        res["rccl_ranks"] = dist.get_world_size()
+        res["collective_backend"] = backend
+        if backend == "nccl" and not args.no_graph_collective:
+            res["graph_collective"] = _guarded(lambda: graph_collective(ops, sweep[len(sweep) // 2], ar_buf), 120.0,
+                                               res, rank)
 
-    tr = REPO / "profiles" / "traffic_latest.json"
-    if tr.exists():  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-        t = json.loads(tr.read_text())
-        res["roofline"]["traffic"] = t.get("suffix_hbm_bytes_per_launch")
-        res["roofline"]["traffic_source"] = t.get("source")
-        res["roofline_prefix"]["traffic"] = t.get("prefix_hbm_bytes_per_launch")
-    if rank == 0 and world == 1 and not args.no_nosharing:
-        res["nosharing"] = bench_nosharing(q, sk, sv, k, v, S, B * 1.0, res)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    solo = rank == 0 and world == 1
+    if solo and not args.no_protocol:
+        res["reference_protocol"] = reference_protocol(ops, q, sk, sv, k, v, sweep, args.protocol_iters,
+                                                       with_nosharing=not args.no_nosharing)
+        ns = res["reference_protocol"].get("nosharing_speedup_mean")
+        if ns is not None:
+            res["nosharing_speedup"] = ns
+    if solo and not args.no_accuracy:
+        res["accuracy"] = accuracy(ops, q, sk, sv, k, v, S // 2)
+    if solo and not args.no_model:
+        del ops
+        torch.cuda.empty_cache()
+        try:
+            res["model_decode"] = model_decode(B, P, args.model_new_tokens)
+            res["decode_tokens_per_sec"] = res["model_decode"]["decode_tokens_per_s"]
+        except Exception as ex:  # the attention line above must survive a failure of the model leg
+            res["model_decode"] = {"error": f"{type(ex).__name__}: {ex}"}
+    if solo and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(B, P, Hq, Hkv, D, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_nosharing(q, sk, sv, k, v, S, B, res):
-    """No-sharing FlashAttention-equivalent decode (scripts/microbenchmark.py:91-127 go_baseline with
-    --unique-seq-len): every sequence owns a private [P+S] KV; same suffix kernel, seq_len = P + s."""
-    from hydragen_amd.flash import flash_attention_seqlen
+def _attach_traffic(suffix_roof, prefix_roof, args, world):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes, only when they were collected with THIS
+    command line (same shape and the same suffix schedule); otherwise only the measured traffic / algorithmic ratio."""
+    tr = REPO / "profiles" / "traffic_latest.json"
+    if not tr.exists():
+        return
+    t = json.loads(tr.read_text())
+    same = (world == 1 and t.get("steps") == args.steps and t.get("batch") == args.batch and t.get("prefix") == args.prefix
+            and t.get("max_suffix") == args.max_suffix and t.get("qheads") == args.qheads and t.get("kvheads") == args.kvheads)
+    for roof, key in ((suffix_roof, "suffix"), (prefix_roof, "prefix")):
+        b = t.get(f"{key}_hbm_bytes_per_launch")
+        if b is None:
+            continue
+        roof["traffic_source"] = t.get("source")
+        if same:
+            roof["traffic"] = b
+        if t.get(f"{key}_algorithmic_bytes_per_launch"):
+            roof["traffic_over_algorithmic"] = b / t[f"{key}_algorithmic_bytes_per_launch"]
 
-    Bi, _, Hq, D = q.shape
-    P = sk.shape[1]
+
+def _guarded(fn, seconds, res, rank):
+    """Run an optional leg; if it hangs (a collective that never completes), print the line without it and leave."""
+    def bail():
+        res["graph_collective"] = {"error": f"timed out after {seconds:.0f} s"}
+        if rank == 0:
+            print(json.dumps(res))
+            sys.stdout.flush()
+        os._exit(0)
+
+    timer = threading.Timer(seconds, bail)
+    timer.daemon = True
+    timer.start()
     try:
-        kt = torch.empty(Bi, P + S, sk.shape[2], D, device=q.device, dtype=q.dtype)
-        vt = torch.empty_like(kt)
-        kt[:, :P] = sk
-        vt[:, :P] = sv
-        kt[:, P:] = k
-        vt[:, P:] = v
-    except torch.OutOfMemoryError:
-        return {"error": "not enough HBM for the materialised no-sharing KV"}
-    times = {}
-    for s in (1, S // 2, S):
-        sl = torch.full((Bi,), P + s, dtype=torch.int32, device=q.device)
-        for _ in range(2):
-            flash_attention_seqlen(q, kt, vt, seq_len=sl)
-        torch.cuda.synchronize()
+        return fn()
+    except Exception as ex:
+        return {"error": f"{type(ex).__name__}: {ex}"}
+    finally:
+        timer.cancel()
+
+
+def _capture(fn):
+    """HIP-graph capture after eager warm-ups on a side stream (hydragen/benchmark_utils.py:140-170)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+def _stats(us):
+    t = torch.tensor(us, dtype=torch.float64)
+    mean, std = float(t.mean()), float(t.std()) if len(us) > 1 else 0.0
+    return {"mean_us": mean, "std_us": std, "rstd": std / mean if mean else 0.0, "n": len(us)}
+
+
+def _timed_replays(graph, iters, flush):
+    for _ in range(3):
+        graph.replay()
+    out = []
+    for _ in range(iters):
+        if flush is not None:
+            flush.add_(1)  # 512 MB read-modify-write: evicts L2 and the 256 MB Infinity Cache (microbenchmark.py:24-47)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 5
         e0.record()
-        for _ in range(n):
-            flash_attention_seqlen(q, kt, vt, seq_len=sl)
+        graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        times[s] = e0.elapsed_time(e1) / n * 1e3
-    mean_us = sum(times.values()) / len(times)
-    byts = 2 * 2 * Bi * (P + S // 2) * sk.shape[2] * D
+        out.append(e0.elapsed_time(e1) * 1e3)
+    return out
+
+
+def graph_collective(ops, s, ar_buf):
+    """N > 1: the decode step's attention + its all-reduce inside one HIP graph (llama.py:849-854 captures the
+    whole TP forward, NCCL all-reduce included)."""
+    def fn():
+        ops.fused(s, torch.cuda.current_stream().cuda_stream)
+        dist.all_reduce(ar_buf)
+
+    g = _capture(fn)
+    us = _timed_replays(g, 20, None)
+    return {"suffix_len": s, **_stats(us), "what": "graph replay of hyd_decode_attn_fused + RCCL all-reduce, back to back"}
+
+
+def reference_protocol(ops, q, sk, sv, k, v, sweep, iters, with_nosharing):
+    from hydragen_amd.flash import flash_attention_seqlen
+
+    dev = q.device
+    B, _, Hq, D = q.shape
+    P = sk.shape[1]
+    flush = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=dev)
+    rows = {}
+    for s in sweep:
+        g = _capture(lambda: ops.fused(s, torch.cuda.current_stream().cuda_stream))
+        rows[s] = {"hydragen_flushed": _stats(_timed_replays(g, iters, flush)),
+                   "hydragen_back_to_back": _stats(_timed_replays(g, iters, None))}
+        del g
+    out = {
+        "protocol": "HIP-graph replay of one hyd_decode_attn_fused call, HIP events per replay, 512 MB flush between "
+                    "replays (and the same replays back to back); hydragen/benchmark_utils.py:82-170, scripts/microbenchmark.py:24-47",
+        "iters": iters, "by_suffix_len": rows,
+    }
+    flagged = [s for s, r in rows.items() if r["hydragen_flushed"]["rstd"] > 0.10]  # scripts/synth.py:240-245
+    if flagged:
+        out["rstd_over_10pct_at"] = flagged
+    out["hydragen_flushed_mean_us"] = sum(r["hydragen_flushed"]["mean_us"] for r in rows.values()) / len(rows)
+    out["hydragen_back_to_back_mean_us"] = sum(r["hydragen_back_to_back"]["mean_us"] for r in rows.values()) / len(rows)
+    if not with_nosharing:
+        return out
+    # no-sharing FlashAttention-equivalent (scripts/microbenchmark.py:91-127 go_baseline with --unique-seq-len): every
+    # sequence owns a private [P + S] KV; same HIP suffix kernel with seq_len = P + s
+    S = k.shape[1]
+    try:
+        kt = torch.empty(B, P + S, sk.shape[2], D, device=dev, dtype=q.dtype)
+        vt = torch.empty_like(kt)
+    except torch.OutOfMemoryError:
+        out["nosharing_error"] = "not enough HBM for the materialised no-sharing KV"
+        return out
+    kt[:, :P] = sk
+    vt[:, :P] = sv
+    kt[:, P:] = k
+    vt[:, P:] = v
+    sp = []
+    for s in sweep:
+        sl = torch.full((B,), P + s, dtype=torch.int32, device=dev)
+        g = _capture(lambda: flash_attention_seqlen(q, kt, vt, seq_len=sl))
+        st = _stats(_timed_replays(g, max(4, iters // 4), flush))
+        del g
+        rows[s]["nosharing_flushed"] = st
+        rows[s]["speedup"] = st["mean_us"] / rows[s]["hydragen_flushed"]["mean_us"]
+        sp.append(rows[s]["speedup"])
+    byts = 2 * 2 * B * (P + sweep[-1]) * sk.shape[2] * D
+    out["nosharing_GBs_at_max_suffix"] = byts / (rows[sweep[-1]]["nosharing_flushed"]["mean_us"] * 1e-6) / 1e9
+    out["nosharing_speedup_mean"] = sum(sp) / len(sp)
+    out["nosharing_speedup_min"] = min(sp)
+    return out
+
+
+def accuracy(ops, q, sk, sv, k, v, s):
+    """Measured error of the bf16 operator at this shape: 32 sequences x all heads against fp64 softmax attention over
+    the concatenated [prefix; suffix] keys of the same bf16 inputs (torch, on the GPU)."""
+    ops.fused(s, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    B, _, Hq, D = q.shape
+    g = Hq // sk.shape[2]
+    idx = torch.linspace(0, B - 1, 32, device=q.device).long()
+    qs = q[idx].double()                                          # [n,1,Hq,D]
+    kk = torch.cat([sk.expand(len(idx), -1, -1, -1), k[idx, :s]], 1).double().repeat_interleave(g, 2)
+    vv = torch.cat([sv.expand(len(idx), -1, -1, -1), v[idx, :s]], 1).double().repeat_interleave(g, 2)
+    sc = torch.einsum("bqhd,bkhd->bhqk", qs, kk) / math.sqrt(D)
+    want = torch.einsum("bhqk,bkhd->bqhd", sc.softmax(-1), vv)
+    got = ops.out[idx].double()
+    diff = (got - want).abs()
     return {
-        "us_per_step_at_suffix": times,
-        "tokens_per_sec": Bi / (mean_us * 1e-6),
-        "achieved_GBs_at_mid": byts / (times[S // 2] * 1e-6) / 1e9,
-        "hydragen_speedup": mean_us / res["attn_us_per_step"],
-        "note": "same HIP suffix kernel over a private [P+S] KV per sequence; seq_len = P + s",
+        "dtype": "bf16", "suffix_len": s, "sequences": int(len(idx)),
+        "reference": "fp64 softmax attention over [prefix; suffix] on the same bf16 inputs",
+        "max_abs_err": float(diff.max()), "mean_abs_err": float(diff.mean()),
+        "relative_l2": float((got - want).norm() / want.norm()),
+        "mean_rdiff": float((2 * diff / (got.abs() + want.abs() + 1e-8)).mean()),   # hydragen/utils.py:13-15
+        "bf16_half_ulp_of_max_output": float(want.abs().max()) * 2.0 ** -9,
+    }
+
+
+def model_decode(B, P, new_tokens):
+    """scripts/synth.py protocol: generate(num_return_sequences=B, max_new_tokens=S, temperature=100) from a P-token
+    prompt on a random-weight Llama-2-7B, HIP-graph decode; prefill isolated by a max_new_tokens=1 run (:207-226)."""
+    from hydragen_amd.llama import HydragenLlamaForCausalLM, LlamaConfig
+
+    cfg = LlamaConfig.llama2_7b()
+    cfg.max_position_embeddings = max(cfg.max_position_embeddings, P + new_tokens + 16)
+    dev = "cuda:0"
+    model = HydragenLlamaForCausalLM.from_config(cfg, dtype=torch.bfloat16, device=dev, seed=0)
+    model.graph(True)
+    prompt = torch.randint(1, cfg.vocab_size, (1, P), device=dev)
+    model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=new_tokens + 16, max_shared_batch_sizes=[1],
+                       max_shared_seq_lengths=[P])
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.generate(input_ids=prompt, num_return_sequences=B, max_new_tokens=n, temperature=100.0)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(4)  # warm-up incl. graph capture
+    full = min(run(new_tokens) for _ in range(2))
+    pre = min(run(1) for _ in range(2))
+    dec = full - pre
+    return {
+        "model": "Llama-2-7B architecture, random weights, bf16, HIP-graph decode", "batch": B, "prefix": P,
+        "new_tokens": new_tokens, "total_s": full, "prefill_s": pre, "decode_s": dec,
+        "decode_tokens_per_s": B * (new_tokens - 1) / dec, "ms_per_decode_step": dec / (new_tokens - 1) * 1e3,
+        "protocol": "scripts/synth.py:33-79,207-226",
     }
 
 

@@ -14,6 +14,7 @@ from pathlib import Path
 HYD_MAX_LEVELS = 8
 HYD_F16, HYD_BF16, HYD_F32 = 0, 1, 2
 HYD_LSE_BQH, HYD_LSE_BHQ = 0, 1
+HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE = 0, 1, 2
 
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libhydragen_hip.so"
 
@@ -63,7 +64,7 @@ class Level(C.Structure):
 class DecodeParams(C.Structure):
     _fields_ = [
         ("suffix", SuffixParams), ("levels", Level * HYD_MAX_LEVELS),
-        ("n_levels", C.c_int32), ("reserved", C.c_int32),
+        ("n_levels", C.c_int32), ("phase", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
@@ -78,7 +79,7 @@ class RopeParams(C.Structure):
         ("vc_batch_stride", C.c_int64), ("vc_tok_stride", C.c_int64), ("vc_head_stride", C.c_int64),
         ("pos_stride", C.c_int64), ("cs_stride", C.c_int64),
         ("dtype", C.c_int32), ("B", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32), ("D", C.c_int32),
-        ("cache_len", C.c_int32),
+        ("cache_len", C.c_int32), ("max_pos", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -94,7 +95,6 @@ EXPORTS = {
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hyd_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeParams)]),
     "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
-    "hyd_decode_attn_fused_timed": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p, C.c_void_p]),
     "hyd_rope_append_decode": (C.c_int, [C.POINTER(RopeParams), C.c_void_p]),
     "hyd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

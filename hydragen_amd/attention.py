@@ -20,7 +20,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import HYD_F32, HYD_LSE_BQH, HYD_MAX_LEVELS, DecodeParams
 from .flash import (
-    _dtype_code, _lastdim_contig, _require_gpu, _stream, fill_suffix_params, prefix_attention,
+    _dtype_code, _lastdim_contig, _q_contig, _require_gpu, _stream, fill_suffix_params, prefix_attention,
 )
 
 
@@ -123,7 +123,7 @@ def hydragen_attention(
         raise NotImplementedError(f"at most {HYD_MAX_LEVELS} shared levels")
 
     b, nq, hq, d = q.shape
-    q = q.contiguous()
+    q = _q_contig(q)
     k, v = _lastdim_contig(k), _lastdim_contig(v)
     shared_ks = [_lastdim_contig(x) for x in shared_ks]
     shared_vs = [_lastdim_contig(x) for x in shared_vs]

@@ -26,6 +26,18 @@ constexpr int kMaxSplits = 32;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Development switches exist only in HYD_ABLATION_BUILD libraries (A/B measurements on hardware); the product library
+// reads no environment variable and keeps no mutable state.
+inline int dev_switch(const char* name) {
+#ifdef HYD_ABLATION_BUILD
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
+
 struct PrefixPlan {
     int g, per, row_blocks, nsplit, split_len, grid, qpg, wg_rows;
 };
@@ -38,7 +50,7 @@ int check_common(int dtype, int B, int nq, int Hq, int Hkv, int D) {
     return HYD_OK;
 }
 
-int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
+int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMaxSplits) {
     if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
     int rc = check_common(p->dtype, p->B, p->nq, p->Hq, p->Hkv, p->D);
     if (rc) return rc;
@@ -61,18 +73,11 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
     pl->row_blocks = (int)((mrows + 127) / 128);
     pl->wg_rows = 128;
     {
-        // 256-row workgroups (pipelined kernel, D = 128) when 128-row ones would need more than one round of the chip
-        // anyway: half the K/V staging per flop and no cross-half merge.  HYD_PREFIX_ROWS=128|256 forces either (A/B).
-        static const int force_rows = [] {
-            const char* e = getenv("HYD_PREFIX_ROWS");
-            return e ? atoi(e) : 0;
-        }();
-        static const bool w8 = [] {
-            const char* e = getenv("HYD_PREFIX_IMPL");
-            return e && !strcmp(e, "w8");
-        }();
+        // 256-row workgroups (D = 128) when 128-row ones would need more than one round of the chip anyway: half the
+        // K/V staging per flop and no cross-half merge.
+        const int force_rows = dev_switch("HYD_PREFIX_ROWS");  // 0 in product builds
         const int64_t units128 = (int64_t)p->sb * p->Hkv * pl->row_blocks;
-        const bool can = p->D == 128 && !w8;
+        const bool can = p->D == 128;
         if (can && (force_rows == 256 || (force_rows == 0 && units128 > kNumCU))) {
             pl->wg_rows = 256;
             pl->row_blocks = (int)((mrows + 255) / 256);
@@ -92,7 +97,8 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl) {
         }
     }
     if (p->cu_seqlens_q) ns = 1;  // merged LSE re-layout needs uniform query counts
-    if (ns > kMaxSplits) ns = kMaxSplits;
+    if (max_splits > kMaxSplits) max_splits = kMaxSplits;
+    if (ns > max_splits) ns = max_splits;
     if (ns < 1) ns = 1;
     int split_len = (int)align_up((size_t)((p->kv_len + ns - 1) / ns), 128);
     if (split_len == 0) split_len = 128;
@@ -138,24 +144,13 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->split_len = pl.split_len;
     a->lse_q_stride = pl.qpg;
     a->scale_log2e = (1.0f / sqrtf((float)p->D)) * kLog2e;
-#ifdef HYD_ABLATION_BUILD
-    static const int dbg = getenv("HYD_DBG") ? atoi(getenv("HYD_DBG")) : 0;  // timing experiments only
-    a->dbg = dbg;
-#else
-    a->dbg = 0;
-#endif
+    a->dbg = dev_switch("HYD_DBG");  // timing-ablation kernel variants; always 0 in product builds
 }
 
 // Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
 // `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
-// The prefix pass runs the software-pipelined kernel (prefix_attn_pl.hip).  The earlier phase-separated kernel
-// (prefix_attn.hip) stays selectable with HYD_PREFIX_IMPL=w8 for A/B measurements on hardware.
 int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
-    static const bool w8 = [] {
-        const char* e = getenv("HYD_PREFIX_IMPL");
-        return e && !strcmp(e, "w8");
-    }();
-    return w8 ? launch_prefix(a, dtype, D, causal, grid, s) : launch_prefix_pl(a, dtype, D, causal, grid, s);
+    return launch_prefix_pl(a, dtype, D, causal, grid, s);
 }
 
 int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s) {
@@ -318,11 +313,7 @@ void level_to_prefix(const hyd_decode_params* p, int i, hyd_prefix_params* pp) {
 // level is the matrix-core suffix kernel's problem with "sequence" = group: nq' = per * nq query tokens per group
 // over the group's P keys, one wave per (group, kv head, 16-row chunk).  Shapes-only decision (capture-safe).
 bool level_is_small(const hyd_prefix_params& pp, const PrefixPlan& pl) {
-    static const bool off = [] {
-        const char* e = getenv("HYD_LEVEL_IMPL");
-        return e && !strcmp(e, "prefix");
-    }();
-    if (off || pp.cu_seqlens_k || pp.cu_seqlens_q || pp.causal) return false;
+    if (dev_switch("HYD_LEVEL_PREFIX") || pp.cu_seqlens_k || pp.cu_seqlens_q || pp.causal) return false;
     if (pp.D != 64 && pp.D != 128) return false;
     const int64_t rows = (int64_t)pl.qpg * pl.g;  // query rows per (group, kv head)
     if (rows > 64 || pp.kv_len > 1024) return false;
@@ -343,6 +334,10 @@ int run_level_small(const hyd_prefix_params& pp, const PrefixPlan& pl, void* out
     const int rc = launch_suffix_gqa(a, pp.dtype, pp.D, s);
     return rc ? fail(HYD_ERR_LAUNCH, "small-level kernel launch failed: hip error %d", rc) : HYD_OK;
 }
+
+// The suffix epilogue merges at most kMaxCombine partials, so the levels of one decode call share that budget:
+// each level may cut its keys into at most kMaxCombine / n_levels slices (>= 8 with HYD_MAX_LEVELS = 8).
+int level_split_cap(int n_levels) { return n_levels > 0 ? kMaxCombine / n_levels : kMaxSplits; }
 
 // per-level workspace: nsplit == 1 -> one dtype slice + lse; nsplit > 1 -> fp32 slices (prefix_ws_bytes)
 size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl) {
@@ -451,6 +446,7 @@ int hyd_rope_append_decode(const hyd_rope_params* p, void* stream) {
         return rc;
     if (p->cs_stride % 4 != 0) return fail(HYD_ERR_BAD_ARG, "cos/sin row stride must be a multiple of 4 floats");
     if (p->cache_len <= 0) return fail(HYD_ERR_BAD_ARG, "cache_len %d", p->cache_len);
+    if (p->max_pos <= 0) return fail(HYD_ERR_BAD_ARG, "max_pos %d: the cos/sin tables need at least one row", p->max_pos);
     RopeArgs a;
     memset(&a, 0, sizeof(a));
     a.q = p->q; a.k = p->k; a.v = p->v; a.q_out = p->q_out; a.k_cache = p->k_cache; a.v_cache = p->v_cache;
@@ -459,19 +455,30 @@ int hyd_rope_append_decode(const hyd_rope_params* p, void* stream) {
     a.kc_bs = p->kc_batch_stride; a.kc_ts = p->kc_tok_stride; a.kc_hs = p->kc_head_stride;
     a.vc_bs = p->vc_batch_stride; a.vc_ts = p->vc_tok_stride; a.vc_hs = p->vc_head_stride;
     a.pos_stride = p->pos_stride; a.cs_stride = p->cs_stride;
-    a.B = p->B; a.Hq = p->Hq; a.Hkv = p->Hkv; a.cache_len = p->cache_len;
+    a.B = p->B; a.Hq = p->Hq; a.Hkv = p->Hkv; a.cache_len = p->cache_len; a.max_pos = p->max_pos;
     rc = launch_rope_append(a, p->dtype, p->D, static_cast<hipStream_t>(stream));
     return rc ? fail(HYD_ERR_LAUNCH, "rope_append kernel launch failed: hip error %d", rc) : HYD_OK;
 }
 
+// attention.py:273-274: a single shared level and no unique keys -> the prefix result IS the answer
+static bool decode_is_prefix_only(const hyd_decode_params* p) { return p->n_levels == 1 && p->suffix.kv_len == 0; }
+
 size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {
     if (!p || p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return 0;
+    if (decode_is_prefix_only(p)) {
+        // written straight to `out` by the prefix pass; only its split-KV slices (if any) need scratch
+        hyd_prefix_params pp;
+        level_to_prefix(p, 0, &pp);
+        PrefixPlan pl;
+        if (plan_prefix(&pp, &pl)) return 0;
+        return prefix_ws_bytes(&pp, pl);
+    }
     size_t total = 0;
     for (int i = 0; i < p->n_levels; ++i) {
         hyd_prefix_params pp;
         level_to_prefix(p, i, &pp);
         PrefixPlan pl;
-        if (plan_prefix(&pp, &pl)) return 0;
+        if (plan_prefix(&pp, &pl, level_split_cap(p->n_levels))) return 0;
         total += level_ws_bytes(pp, pl);
     }
     return total;
@@ -496,25 +503,27 @@ size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32
     return hyd_decode_workspace_bytes(&p);
 }
 
-int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) { return hyd_decode_attn_fused_timed(p, stream, nullptr); }
-
-int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* event_after_prefix) {
+int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
     if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
     if (p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return fail(HYD_ERR_BAD_ARG, "n_levels %d", p->n_levels);
+    if (p->phase != HYD_PHASE_ALL && p->phase != HYD_PHASE_SHARED && p->phase != HYD_PHASE_UNIQUE)
+        return fail(HYD_ERR_BAD_ARG, "phase %d", p->phase);
     const hyd_suffix_params& sp = p->suffix;
     int rc = check_suffix(&sp, true);
     if (rc) return rc;
     if (p->n_levels == 0 && sp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "no shared levels and no unique keys");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t rows = (size_t)sp.B * sp.nq * sp.Hq;
+    const bool do_shared = p->phase != HYD_PHASE_UNIQUE, do_unique = p->phase != HYD_PHASE_SHARED;
 
-    // attention.py:273-274: single level, empty unique KV -> the prefix result is the answer
-    if (p->n_levels == 1 && sp.kv_len == 0) {
+    if (decode_is_prefix_only(p)) {
+        if (!do_shared) return HYD_OK;  // nothing left for the unique phase
         hyd_prefix_params pp;
         level_to_prefix(p, 0, &pp);
         PrefixPlan pl;
         if ((rc = plan_prefix(&pp, &pl))) return rc;
         if ((rc = check_prefix_ptrs(&pp))) return rc;
+        if (pp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "level 0 has kv_len == 0");
         pp.out = sp.out;
         pp.lse = nullptr;
         pp.workspace = p->workspace;
@@ -522,22 +531,33 @@ int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* 
         return run_prefix(&pp, pl, true, s);
     }
 
-    const size_t need = hyd_decode_workspace_bytes(p);
+    // ---- plan and validate everything before the first launch ----------------------------------------------
+    hyd_prefix_params pps[HYD_MAX_LEVELS];
+    PrefixPlan pls[HYD_MAX_LEVELS];
+    bool small[HYD_MAX_LEVELS];
+    size_t bytes[HYD_MAX_LEVELS];
+    size_t need = 0;
+    int n_parts = 0;
+    for (int i = 0; i < p->n_levels; ++i) {
+        level_to_prefix(p, i, &pps[i]);
+        if ((rc = plan_prefix(&pps[i], &pls[i], level_split_cap(p->n_levels)))) return rc;
+        if ((rc = check_prefix_ptrs(&pps[i]))) return rc;
+        if (pps[i].kv_len == 0) return fail(HYD_ERR_BAD_ARG, "level %d has kv_len == 0", i);
+        small[i] = level_is_small(pps[i], pls[i]);
+        bytes[i] = level_ws_bytes(pps[i], pls[i]);
+        need += bytes[i];
+        n_parts += (pls[i].nsplit == 1 || small[i]) ? 1 : pls[i].nsplit;
+    }
+    if (n_parts > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "%d partials (more than %d)", n_parts, kMaxCombine);
     if (need > 0 && (!p->workspace || p->workspace_bytes < need))
         return fail(HYD_ERR_WORKSPACE, "decode needs %zu workspace bytes, got %zu", need, p->workspace_bytes);
 
     hyd_partial parts[HYD_MAX_LEVELS];
     char* ws = static_cast<char*>(p->workspace);
     for (int i = 0; i < p->n_levels; ++i) {
-        hyd_prefix_params pp;
-        level_to_prefix(p, i, &pp);
-        PrefixPlan pl;
-        if ((rc = plan_prefix(&pp, &pl))) return rc;
-        if ((rc = check_prefix_ptrs(&pp))) return rc;
-        if (pp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "level %d has kv_len == 0", i);
-        const size_t bytes = level_ws_bytes(pp, pl);
-        const bool small = level_is_small(pp, pl);
-        if (pl.nsplit == 1 || small) {
+        hyd_prefix_params& pp = pps[i];
+        const PrefixPlan& pl = pls[i];
+        if (pl.nsplit == 1 || small[i]) {
             pp.out = ws;
             pp.lse = reinterpret_cast<float*>(ws + align_up(rows * sp.D * 2, 256));
             parts[i].out = pp.out;
@@ -546,18 +566,20 @@ int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* 
             parts[i].is_f32 = 0;
         } else {
             pp.workspace = ws;
-            pp.workspace_bytes = bytes;
+            pp.workspace_bytes = bytes[i];
             parts[i].out = ws;
             parts[i].lse = reinterpret_cast<const float*>(ws + (size_t)pl.nsplit * align_up(rows * sp.D * 4, 256));
             parts[i].count = pl.nsplit;
             parts[i].is_f32 = 1;
         }
-        if (small) rc = run_level_small(pp, pl, const_cast<void*>(parts[i].out), const_cast<float*>(parts[i].lse), s);
-        else rc = run_prefix(&pp, pl, /*merge=*/false, s);
-        if (rc) return rc;
-        ws += bytes;
+        if (do_shared) {
+            if (small[i]) rc = run_level_small(pp, pl, const_cast<void*>(parts[i].out), const_cast<float*>(parts[i].lse), s);
+            else rc = run_prefix(&pp, pl, /*merge=*/false, s);
+            if (rc) return rc;
+        }
+        ws += bytes[i];
     }
-    if (event_after_prefix) (void)hipEventRecord(static_cast<hipEvent_t>(event_after_prefix), s);
+    if (!do_unique) return HYD_OK;
     if (sp.kv_len == 0) {
         // several levels, no unique keys: merge the level partials only (suffix contributes lse = -inf)
         hyd_suffix_params s0 = sp;

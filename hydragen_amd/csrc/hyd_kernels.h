@@ -78,11 +78,10 @@ struct RopeArgs {
     int64_t q_bs, k_bs, v_bs;          // batch strides of q/k/v (elements); heads contiguous
     int64_t kc_bs, kc_ts, kc_hs, vc_bs, vc_ts, vc_hs;
     int64_t pos_stride, cs_stride;
-    int32_t B, Hq, Hkv, cache_len;
+    int32_t B, Hq, Hkv, cache_len, max_pos;
 };
 
 // launchers (defined next to the kernels); return hipError_t as int
-int launch_prefix(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
 int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
 int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);

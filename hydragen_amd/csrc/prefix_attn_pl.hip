@@ -563,12 +563,10 @@ template <typename T, int D, bool CAUSAL, int ABL = 0, int KG = 2>
 static int launch_prefix_pl_t(const PrefixArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (KG == 2 ? 2 : 1) * 256 * (D * 2) + 8 * 128 * sizeof(float);
     auto kern = prefix_attn_pl_kernel<T, D, CAUSAL, ABL, KG>;
-    static bool attr_set = false;  // idempotent; value never changes
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
+    // once per instantiation, thread-safe (C++11 static initialisation); the value never changes afterwards
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_rc != hipSuccess) return (int)attr_rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
     return (int)hipGetLastError();
 }

@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const RopeArgs a) {
     if (row >= (int64_t)a.B * rows_per_b) return;
     const int b = (int)(row / rows_per_b);
     const int h = (int)(row % rows_per_b);
-    const int64_t pos = a.pos[(int64_t)b * a.pos_stride];
-    const int64_t idx = pos - (a.shared_len ? a.shared_len[b] : 0);
+    const int64_t pos_raw = a.pos[(int64_t)b * a.pos_stride];
+    const int64_t idx = pos_raw - (a.shared_len ? a.shared_len[b] : 0);
+    // never read past the rotary tables (the host checks the range before launching; a kernel cannot raise)
+    const int64_t pos = pos_raw < 0 ? 0 : (pos_raw >= a.max_pos ? (int64_t)a.max_pos - 1 : pos_raw);
     if (h == 0 && sub == 0) a.seq_lens[b] = (int32_t)(idx + 1);
     const int d0 = sub * 8;
     if (h < a.Hq + a.Hkv) {

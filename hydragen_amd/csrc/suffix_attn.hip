@@ -385,12 +385,16 @@ static int launch_suffix_t(const SuffixArgs& a, hipStream_t s) {
 }
 
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s) {
-    // grouped-query shapes go to the matrix-core kernel (suffix_attn_gqa.hip).  HYD_SUFFIX_IMPL=valu keeps them here,
-    // HYD_SUFFIX_IMPL=gqa sends every shape the other kernel can address there (A/B runs and test coverage).
+    // grouped-query shapes go to the matrix-core kernel (suffix_attn_gqa.hip).  Development builds only
+    // (HYD_ABLATION_BUILD): HYD_SUFFIX_IMPL=valu keeps them here, =gqa sends every addressable shape there.
+#ifdef HYD_ABLATION_BUILD
     static const int force = [] {
         const char* e = getenv("HYD_SUFFIX_IMPL");
         return !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "gqa") ? 2 : 0;
     }();
+#else
+    constexpr int force = 0;
+#endif
     if (force != 1 && suffix_gqa_eligible(a, D, force == 2)) return launch_suffix_gqa(a, dtype, D, s);
     if (dtype == HYD_F16) {
         if (D == 128) return launch_suffix_t<F16, 128>(a, s);

@@ -52,9 +52,18 @@ def _lastdim_contig(t: Tensor) -> Tensor:
     """K/V may be arbitrary views as long as head_dim is contiguous and strides are 16B-aligned."""
     if t.is_contiguous() and t.data_ptr() % 16 == 0 and t.shape[-1] % 8 == 0:  # the common case, one C call
         return t
-    if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]) or t.data_ptr() % 16:
+    if t.data_ptr() % 16:  # a view at an odd storage offset: .contiguous() would hand the same memory back
+        return t.clone(memory_format=torch.contiguous_format)
+    if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]):
         return t.contiguous()
     return t
+
+
+def _q_contig(q: Tensor) -> Tensor:
+    """q / out are addressed as dense [.., Hq, D] rows with 16-byte accesses."""
+    if q.data_ptr() % 16:
+        return q.clone(memory_format=torch.contiguous_format)
+    return q.contiguous()
 
 
 def prefix_attention(
@@ -111,7 +120,7 @@ def flash_attention(q: Tensor, k: Tensor, v: Tensor, causal: bool = False) -> tu
     assert k.shape == v.shape, f"{k.shape} {v.shape}"
     b, sq, hq, d = q.shape
     assert k.shape[0] == b and k.shape[3] == d, f"{q.shape} {k.shape}"
-    q = q.contiguous()
+    q = _q_contig(q)
     k, v = _lastdim_contig(k), _lastdim_contig(v)
     return prefix_attention(
         q, k, v, sb=b, kv_len=k.shape[1], group_stride=(k.stride(0), v.stride(0)),
@@ -139,7 +148,7 @@ def flash_attention_varlen(
     assert cu_seqlens_q.shape == cu_seqlens_k.shape
     nseq = cu_seqlens_q.shape[0] - 1
     tq, hq, d = q.shape
-    q = q.contiguous()
+    q = _q_contig(q)
     k, v = _lastdim_contig(k), _lastdim_contig(v)
     return prefix_attention(
         q, k, v, sb=nseq, kv_len=int(max_seqlen_k), group_stride=(0, 0),
@@ -192,7 +201,7 @@ def flash_attention_seqlen(raw_q: Tensor, raw_k: Tensor, raw_v: Tensor, seq_len=
         f"Keys have head dim {raw_k.shape[-1]} but queries have head dim {raw_q.shape[-1]}"
     )
     lib = _lib.load()
-    q = raw_q.contiguous()
+    q = _q_contig(raw_q)
     k, v = _lastdim_contig(raw_k), _lastdim_contig(raw_v)
     out = torch.empty_like(q)
     lse = torch.empty(q.shape[:3], dtype=torch.float32, device=q.device)

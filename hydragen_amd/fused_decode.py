@@ -45,5 +45,6 @@ def rope_append_decode(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor
     p.vc_batch_stride, p.vc_tok_stride, p.vc_head_stride = v_cache.stride(0), v_cache.stride(1), v_cache.stride(2)
     p.pos_stride, p.cs_stride = position_ids.stride(0), cos.stride(0)
     p.dtype, p.B, p.Hq, p.Hkv, p.D, p.cache_len = _dtype_code(q), B, Hq, Hkv, D, k_cache.shape[1]
+    p.max_pos = cos.shape[0]
     _lib.check(lib.hyd_rope_append_decode(C.byref(p), _stream()))
     return q_out, seq_lens

@@ -536,8 +536,15 @@ class HydragenLlamaForCausalLM(nn.Module):
                           c.num_key_value_heads, c.vocab_size, c.rms_norm_eps,
                           getattr(c, "rope_theta", rp.get("rope_theta", 10000.0)), c.max_position_embeddings,
                           getattr(c, "attention_bias", False), c.pad_token_id)  # pragma: no cover
+        scaling = getattr(c, "rope_scaling", None) or {}  # pragma: no cover
+        kind = scaling.get("rope_type", scaling.get("type", "default")) or rp.get("rope_type", "default")  # pragma: no cover
+        if kind not in ("default", None):  # pragma: no cover
+            raise NotImplementedError(f"rope scaling '{kind}' is not implemented (plain theta-only RoPE tables)")
         model = cls(cfg)  # pragma: no cover
-        model.load_state_dict(hf.state_dict(), strict=False)  # pragma: no cover
+        report = model.load_state_dict(hf.state_dict(), strict=False)  # pragma: no cover
+        extra = [k for k in report.unexpected_keys if "inv_freq" not in k]  # pragma: no cover
+        if report.missing_keys or extra:  # pragma: no cover
+            raise RuntimeError(f"checkpoint does not match: missing {report.missing_keys[:5]}, unexpected {extra[:5]}")
         model.to(device=hf.device, dtype=hf.dtype)  # pragma: no cover
         model.model.rotary_emb.float()  # pragma: no cover
         model.device, model.dtype = hf.device, hf.dtype  # pragma: no cover
@@ -647,6 +654,37 @@ class HydragenLlamaForCausalLM(nn.Module):
         self.set_mode(AttentionMode.UNIQUE_PREFILL)
         return self(input_ids=input_ids, position_ids=self._positions(input_ids), seq_lens=seq_lens)
 
+    # ---- generation -----------------------------------------------------------------------------------
+    # Contract (README.md:183-289 of the reference; llama.py:1156-1396): prompts form a hierarchy, outermost level
+    # first.  With num_return_sequences > 1 every given level is shared and the completions hang off the last one;
+    # otherwise the last given level is each sequence's own (unique) prompt.  shared_cache_op: "wipe" empties the
+    # shared caches first, "preserve" drops the levels this call added when it returns, "extend" keeps them.
+    def _prompt_levels(self, input_ids, seq_lens, fan_out, flatten_last):
+        """-> (shared levels [(ids, lens)], unique level (ids, lens) or None)."""
+        levels = [] if input_ids is None else ([input_ids] if isinstance(input_ids, Tensor) else list(input_ids))
+        if seq_lens is None:
+            lens = [torch.full((x.shape[0],), x.shape[1], device=x.device, dtype=torch.long) for x in levels]
+        else:
+            lens = [seq_lens] if isinstance(seq_lens, Tensor) else list(seq_lens)
+        pairs = list(zip(levels, lens))
+        if not pairs or (fan_out and not flatten_last):
+            return pairs, None
+        return pairs[:-1], pairs[-1]
+
+    def _check_room(self, start_positions, new_tokens):
+        """The fused decode preamble cannot raise from the device: refuse on the host anything that would index past
+        the unique cache or the rotary tables (the reference's scatter_/index ops device-assert)."""
+        if new_tokens < 2:
+            return  # the first token comes from the prefill logits: no decode step runs
+        room = self.model.layers[0].self_attn.kv_cache.per_completion_k_cache.shape[1]
+        last_pos = int(start_positions.max().item()) + new_tokens - 2
+        shared = 0 if self.model.get_disable_hydragen() else int(self.get_shared_cache_len(start_positions.shape[0]).min().item())
+        last_idx = last_pos - shared
+        if last_idx >= room:
+            raise ValueError(f"unique cache holds {room} tokens per sequence, decoding needs {last_idx + 1}")
+        if last_pos >= self.config.max_position_embeddings:
+            raise ValueError(f"position {last_pos} exceeds max_position_embeddings = {self.config.max_position_embeddings}")
+
     @torch.no_grad()
     def generate(self, input_ids: Optional[Union[Tensor, list[Tensor]]] = None,
                  seq_lens: Optional[Union[Tensor, list[Tensor]]] = None, starting_logits: Optional[Tensor] = None,
@@ -655,92 +693,71 @@ class HydragenLlamaForCausalLM(nn.Module):
                  shared_cache_op: str = SharedCacheOp.PRESERVE, disable_hydragen: bool = False,
                  disable_attention: bool = False, disable_hierarchy: bool = False,
                  token_overrides: Optional[Tensor] = None):
-        """Same contract as llama.py:1156-1396 (hierarchical prompts as a list of id tensors, last level
-        optionally multiplied by num_return_sequences; shared_cache_op wipe/preserve/extend; the
-        disable_* switches are the paper's baselines; token_overrides forces tokens for testing)."""
-        assert self.kv_cache_allocated
-        assert (input_ids is None) or (starting_logits is None)
-        assert not (input_ids is None and starting_logits is None)
-        if input_ids is None:
-            input_ids = []
+        if not self.kv_cache_allocated:
+            raise RuntimeError("call setup_caches() before generate()")
+        if (input_ids is None) == (starting_logits is None):
+            raise ValueError("pass exactly one of input_ids and starting_logits")
         if temperature < 0:
             raise ValueError(f"temperature must be non-negative, {temperature} is invalid")
-        if disable_attention:
-            self.model.set_disable_attention(True)
+        fan_out = num_return_sequences > 1
+        flatten = disable_hierarchy or disable_hydragen  # the baselines keep the last level per sequence
         if shared_cache_op == SharedCacheOp.WIPE:
             self.empty_shared_cache()
-        og = self.get_num_used_shared_caches()
-        if isinstance(input_ids, Tensor):
-            input_ids = [input_ids]
-        num_new_levels = len(input_ids) + (1 if num_return_sequences > 1 else 0)
-        total_levels = og + num_new_levels
-        if disable_hydragen:
-            assert total_levels == 2
-            if num_new_levels == 2:
-                assert input_ids[0].shape[0] == 1
-        if disable_hierarchy:
-            assert total_levels == 3 and num_return_sequences > 1
-        if isinstance(seq_lens, Tensor):
-            seq_lens = [seq_lens]
-        elif seq_lens is None:
-            seq_lens = [torch.full((x.shape[0],), x.shape[1], device=x.device, dtype=torch.long) for x in input_ids]
-        if len(input_ids) > 0:
-            total_batch_size = input_ids[-1].shape[0] * num_return_sequences
-        else:
-            total_batch_size = starting_logits.shape[0] * num_return_sequences
+        levels_before = self.get_num_used_shared_caches()
+        shared, unique = self._prompt_levels(input_ids, seq_lens, fan_out, flatten)
+        n_given = len(shared) + (unique is not None)
+        depth = levels_before + n_given + (1 if fan_out else 0)
+        if disable_hydragen and (depth != 2 or (n_given == 2 and shared[0][0].shape[0] != 1)):
+            raise ValueError("disable_hydragen compares against ONE shared prompt: exactly two levels, the first of batch 1")
+        if disable_hierarchy and not (depth == 3 and fan_out):
+            raise ValueError("disable_hierarchy flattens a three-level hierarchy with num_return_sequences > 1")
 
-        if num_return_sequences > 1 and not (disable_hierarchy or disable_hydragen):
-            shared_ids, shared_seq_lens, suffix_ids, suffix_seq_lens = input_ids, seq_lens, None, None
-        elif len(input_ids) > 0:
-            shared_ids, shared_seq_lens = input_ids[:-1], seq_lens[:-1]
-            suffix_ids, suffix_seq_lens = input_ids[-1], seq_lens[-1]
-        else:
-            shared_ids, shared_seq_lens, suffix_ids, suffix_seq_lens = [], [], None, None
-
-        if starting_logits is not None:
-            starting_logits = starting_logits.unsqueeze(1)
-        for sid, slen in zip(shared_ids, shared_seq_lens):
-            starting_logits = self.append_shared(sid, slen)
+        self.model.set_disable_attention(bool(disable_attention))
+        logits = None if starting_logits is None else starting_logits.unsqueeze(1)
+        for ids, lens in shared:
+            logits = self.append_shared(ids, lens)
+        leaf_batch = (unique[0].shape[0] if unique is not None else logits.shape[0])
+        batch = leaf_batch * num_return_sequences
         if disable_hydragen:
             self.model.set_disable_hydragen(True)
             if self.get_num_used_shared_caches() > 0:
-                self.model.copy_shared_cache_to_unique(total_batch_size)
-        if suffix_ids is not None:
-            starting_logits = self.process_unique(suffix_ids, suffix_seq_lens)
-            self.repeat_per_completion_cache_for_num_samples(suffix_ids.shape[0], num_return_sequences)
+                self.model.copy_shared_cache_to_unique(batch)
+        if unique is not None:
+            logits = self.process_unique(*unique)
+            self.repeat_per_completion_cache_for_num_samples(unique[0].shape[0], num_return_sequences)
 
-        prefill_logits = starting_logits[:, -1]
-        first = self.sample_from_logits(prefill_logits, temperature=temperature, num_samples=num_return_sequences, top_p=top_p)
-        first_token_ids = first.reshape(-1, 1)
-        logits_to_return = [prefill_logits.repeat_interleave(num_return_sequences, 0)] if return_logits else None
-
-        starting_position_ids = self.get_shared_cache_len(first_token_ids.shape[0])[:, None]
-        if suffix_seq_lens is not None:
-            starting_position_ids = starting_position_ids + suffix_seq_lens.long().repeat_interleave(num_return_sequences, 0)[:, None]
-        finished = (first_token_ids == eos_token_id) if eos_token_id is not None else None
-        decoded = [first_token_ids]
-        current = first_token_ids if token_overrides is None else token_overrides[:, 0:1]
-
-        self.set_mode(AttentionMode.DECODE)
-        for i in range(max_new_tokens - 1):
-            position_ids = starting_position_ids + i
-            logits = self(input_ids=current, position_ids=position_ids, use_graph=self.graphed_model is not None)
-            if return_logits:
-                logits_to_return.append(logits[:, -1])
-            current = self.sample_from_logits(logits[:, -1], temperature=temperature, top_p=top_p)
-            if finished is not None:
-                finished = torch.logical_or(finished, current == eos_token_id)
-                if torch.all(finished):
-                    break
-            decoded.append(current)
-            if token_overrides is not None:
-                current = token_overrides[:, i + 1 : i + 2]
-        out = torch.cat(decoded, dim=-1)
-
-        if shared_cache_op == SharedCacheOp.PRESERVE:
-            self.truncate_shared_caches(og)
-        if disable_hydragen:
+        try:
+            return self._decode(logits[:, -1], unique, num_return_sequences, max_new_tokens, temperature, top_p,
+                                eos_token_id, return_logits, token_overrides)
+        finally:
+            if shared_cache_op == SharedCacheOp.PRESERVE:
+                self.truncate_shared_caches(levels_before)
             self.model.set_disable_hydragen(False)
-        if disable_attention:
             self.model.set_disable_attention(False)
-        return (out, logits_to_return) if return_logits else out
+
+    def _decode(self, prefill_logits, unique, fan, max_new_tokens, temperature, top_p, eos_token_id, return_logits,
+                token_overrides):
+        first = self.sample_from_logits(prefill_logits, temperature=temperature, num_samples=fan, top_p=top_p).reshape(-1, 1)
+        kept_logits = [prefill_logits.repeat_interleave(fan, 0)] if return_logits else None
+        start = self.get_shared_cache_len(first.shape[0])[:, None]
+        if unique is not None:
+            start = start + unique[1].long().repeat_interleave(fan, 0)[:, None]
+        self._check_room(start, max_new_tokens)
+        done = (first == eos_token_id) if eos_token_id is not None else None
+        tokens = [first]
+        feed = first if token_overrides is None else token_overrides[:, 0:1]
+        self.set_mode(AttentionMode.DECODE)
+        graphed = self.graphed_model is not None
+        for step in range(max_new_tokens - 1):
+            logits = self(input_ids=feed, position_ids=start + step, use_graph=graphed)[:, -1]
+            if return_logits:
+                kept_logits.append(logits)
+            nxt = self.sample_from_logits(logits, temperature=temperature, top_p=top_p)
+            if done is not None:
+                done = done | (nxt == eos_token_id)
+                if bool(done.all()):
+                    break
+            tokens.append(nxt)
+            feed = nxt if token_overrides is None else token_overrides[:, step + 1 : step + 2]
+        out = torch.cat(tokens, dim=-1)
+        return (out, kept_logits) if return_logits else out

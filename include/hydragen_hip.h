@@ -21,9 +21,9 @@
  *
  * Conventions:
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
- *   - the library never allocates device memory, never synchronises, holds no mutable global
- *     state, and launches only on the hipStream_t passed in (as void*): every call is
- *     HIP-graph-capture safe;
+ *   - the library never allocates device memory, never synchronises, reads no environment
+ *     variable, holds no mutable global state, and launches only on the hipStream_t passed in
+ *     (as void*): every call is HIP-graph-capture safe;
  *   - launch geometry is derived from shapes only, never from device data;
  *   - every call returns HYD_OK (0) or a negative error code; hyd_last_error_string() gives the
  *     message for the calling thread's last failure;
@@ -41,7 +41,10 @@
 extern "C" {
 #endif
 
-#define HYD_VERSION 100 /* 0.1.0 */
+/* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
+#define HYD_API __attribute__((visibility("default")))
+
+#define HYD_VERSION 200 /* 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
 #define HYD_MAX_LEVELS 8
 
 enum {
@@ -87,8 +90,8 @@ typedef struct hyd_prefix_params {
     int32_t num_splits; /* split-KV factor; 0 = choose from shapes                             */
 } hyd_prefix_params;
 
-size_t hyd_prefix_workspace_bytes(const hyd_prefix_params* p);
-int hyd_prefix_attn_fwd(const hyd_prefix_params* p, void* stream);
+HYD_API size_t hyd_prefix_workspace_bytes(const hyd_prefix_params* p);
+HYD_API int hyd_prefix_attn_fwd(const hyd_prefix_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Suffix pass: every query row of sequence b against the first seq_len[b] keys of b's own
@@ -121,14 +124,14 @@ typedef struct hyd_suffix_params {
     hyd_partial partials[HYD_MAX_LEVELS];
 } hyd_suffix_params;
 
-int hyd_suffix_attn_fwd(const hyd_suffix_params* p, void* stream);
+HYD_API int hyd_suffix_attn_fwd(const hyd_suffix_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * combine_lse for N partials (attention.py:21-43): out = sum_i out_i*exp(lse_i-m) / sum_i exp(lse_i-m).
  * rows = B*nq*Hq.  `outs`/`lses` are HOST arrays of n device pointers.  dtype may be HYD_F32.
  * out_lse (may be NULL) receives the merged LSE  m + log(sum_i exp(lse_i - m)).
  * ------------------------------------------------------------------------------------------ */
-int hyd_combine_lse(const void* const* outs, const float* const* lses, int32_t n, int64_t rows, int32_t D,
+HYD_API int hyd_combine_lse(const void* const* outs, const float* const* lses, int32_t n, int64_t rows, int32_t D,
                     int32_t dtype, void* out, float* out_lse, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -147,25 +150,28 @@ typedef struct hyd_level {
     int32_t kv_len;              /* uniform length, or max length when cu_seqlens_k != NULL   */
 } hyd_level;
 
+/* Which part of the operator a call enqueues.  ALL is the normal one-call form.  SHARED runs only the
+ * per-level prefix passes (they read q and the shared caches and fill the workspace); UNIQUE runs only
+ * the suffix pass + merge and expects the workspace as a SHARED call with the same parameters left it.
+ * The two halves touch disjoint inputs (the unique K/V and seq_lens are read by UNIQUE only), so a
+ * caller may run SHARED on one stream while this step's k/v are still being appended on another. */
+enum { HYD_PHASE_ALL = 0, HYD_PHASE_SHARED = 1, HYD_PHASE_UNIQUE = 2 };
+
 typedef struct hyd_decode_params {
     hyd_suffix_params suffix;    /* q, unique k/v, seq_lens, out; n_partials/partials ignored */
     hyd_level levels[HYD_MAX_LEVELS];
     int32_t n_levels;
-    int32_t reserved;
+    int32_t phase;               /* HYD_PHASE_*                                               */
     void* workspace;             /* >= hyd_decode_workspace_bytes()                           */
     size_t workspace_bytes;
 } hyd_decode_params;
 
-size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);
-int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
-/* Measurement aid (bench.py): identical launches, plus hipEventRecord(event_after_prefix, stream) between
- * the last prefix pass and the suffix pass so each kernel can be timed inside the fused call.  Not
- * for use under graph capture. */
-int hyd_decode_attn_fused_timed(const hyd_decode_params* p, void* stream, void* event_after_prefix);
+HYD_API size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);
+HYD_API int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
 
 /* Upper bound helper mirroring SURVEY 8b's `hyd_workspace_bytes(shape...)`: bytes that
  * hyd_decode_attn_fused needs for n_levels uniform levels of the given shapes. */
-size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32_t D, int32_t n_levels,
+HYD_API size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32_t D, int32_t n_levels,
                            const int32_t* level_sb, const int32_t* level_kv_len);
 
 /* ------------------------------------------------------------------------------------------
@@ -192,15 +198,18 @@ typedef struct hyd_rope_params {
     int64_t vc_batch_stride, vc_tok_stride, vc_head_stride;
     int64_t pos_stride, cs_stride;
     int32_t dtype, B, Hq, Hkv, D, cache_len;
+    int32_t max_pos;             /* rows of the cos/sin tables; positions are clamped to it (the  */
+    int32_t reserved;            /*   host checks the range before launching: a kernel cannot raise) */
 } hyd_rope_params;
 
-int hyd_rope_append_decode(const hyd_rope_params* p, void* stream);
+HYD_API int hyd_rope_append_decode(const hyd_rope_params* p, void* stream);
 
-int hyd_version(void);
-const char* hyd_last_error_string(void);
+HYD_API int hyd_version(void);
+HYD_API const char* hyd_last_error_string(void);
 
-/* Diagnostics used by tests/bench: the split-KV factor and grid the prefix pass would use. */
-int hyd_prefix_plan(const hyd_prefix_params* p, int32_t* num_splits, int32_t* grid, int32_t* split_len);
+/* Planner query: the split-KV factor, grid and keys per split the prefix pass derives from these shapes (what
+ * hyd_prefix_workspace_bytes sizes the scratch for). */
+HYD_API int hyd_prefix_plan(const hyd_prefix_params* p, int32_t* num_splits, int32_t* grid, int32_t* split_len);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,20 @@ def test_exports_match_header():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.hyd_version() == 100
+    assert lib.hyd_version() == 200
+
+
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """The product library is built with hidden visibility: `nm -D` must list the header's entry points and nothing
+    else of ours (no measurement exports, no C++ launchers), and the library must not read the environment."""
+    import subprocess
+    header = (REPO / "include" / "hydragen_hip.h").read_text()
+    declared = set(re.findall(r"\b(hyd_[a-z_0-9]+)\s*\(", header))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", str(_lib.lib_path())], text=True)
+    defined = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert defined == declared, defined ^ declared
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", str(_lib.lib_path())], text=True)
+    assert "getenv" not in undefined, "the product library must not read environment variables"
 
 
 def test_struct_layout_matches_c():
@@ -115,6 +128,61 @@ def test_decode_workspace_accounting():
     d.suffix.dtype, d.suffix.B, d.suffix.nq, d.suffix.Hq, d.suffix.Hkv, d.suffix.D = 1, 1024, 1, 32, 32, 128
     d.n_levels = 9
     assert lib.hyd_decode_attn_fused(C.byref(d), None) == -1
+
+
+def _decode(B, Hq, Hkv, D, levels, kv_len=16):
+    d = DecodeParams()
+    d.suffix.dtype, d.suffix.B, d.suffix.nq, d.suffix.Hq, d.suffix.Hkv, d.suffix.D = 1, B, 1, Hq, Hkv, D
+    d.suffix.kv_len = kv_len
+    d.n_levels = len(levels)
+    for i, (sb, n) in enumerate(levels):
+        d.levels[i].sb, d.levels[i].kv_len = sb, n
+    return d
+
+
+def test_prefix_only_early_exit_workspace_covers_the_split_slices():
+    """one shared level + empty unique KV runs the prefix pass with its own split plan, so the decode
+    workspace query must answer with what that pass needs (it used to return the small-level size)."""
+    lib = _lib.load()
+    d = _decode(4, 8, 8, 128, [(1, 1024)], kv_len=0)
+    p = _prefix(B=4, Hq=8, Hkv=8, kv_len=1024)
+    rc, ns, _, _ = _plan(p)
+    assert rc == 0 and ns > 1
+    want = lib.hyd_prefix_workspace_bytes(C.byref(p))
+    assert want >= ns * 4 * 8 * 128 * 4
+    assert lib.hyd_decode_workspace_bytes(C.byref(d)) == want
+
+
+def test_deep_hierarchy_partials_fit_the_merge_budget():
+    """three long levels with one kv head used to plan 3 x 32 = 96 split slices against a merge budget of
+    64.  The levels of one call now share the budget, so the workspace is that of at most 64 // 3 slices per level."""
+    lib = _lib.load()
+    B, Hq, D, n = 64, 8, 128, 16384
+    rows = B * Hq
+    per_slice = rows * D * 4 + rows * 4
+    d = _decode(B, Hq, 1, D, [(1, n), (2, n), (4, n)])
+    ws = lib.hyd_decode_workspace_bytes(C.byref(d))
+    assert 0 < ws <= 3 * (64 // 3) * per_slice
+    one = _decode(B, Hq, 1, D, [(1, n)])
+    assert lib.hyd_decode_workspace_bytes(C.byref(one)) == 32 * per_slice  # a single level keeps its 32 slices
+
+
+def test_phase_argument_is_validated():
+    lib = _lib.load()
+    d = _decode(4, 8, 8, 128, [(1, 64)])
+    d.phase = 7
+    d.suffix.q = d.suffix.out = d.suffix.k = d.suffix.v = 0x10000
+    assert lib.hyd_decode_attn_fused(C.byref(d), None) == -1 and "phase" in lib.hyd_last_error_string().decode()
+
+
+def test_bench_suffix_schedule_is_a_uniform_cover_for_any_step_count():
+    import bench
+    for steps in (8, 20, 100, 128, 256, 300):
+        s = bench.suffix_schedule(steps, 128)
+        assert len(s) == steps and min(s) >= 1 and max(s) <= 128
+        assert abs(sum(s) / steps - 64.5) < 1.0, (steps, sum(s) / steps)
+        assert max(s) - min(s) >= 100
+    assert sorted(bench.suffix_schedule(256, 128)) == sorted(list(range(1, 129)) * 2)
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -93,6 +93,29 @@ def test_fullsize_vs_torch_fp32_subset(name, dt):
     check(out[idx], subset_ref(q, k, v, sks, svs, lens, idx), dt, name)
 
 
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_fullsize_vs_float64_oracle_subset(name, dt):
+    """Every BASELINE configuration at full size, 6 sequences (first, last, middle, ragged extremes) x all heads
+    against the float64 CPU oracle on the very same 16-bit inputs (not only the fp32 torch reference above)."""
+    import numpy as np
+
+    from hydragen_amd.attention import hydragen_attention_nopad
+    from oracle import hydragen_oracle as O
+    from tests.gpu_util import assert_close
+
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float16
+    q, k, v, sks, svs, lens = make(dtype=dtype, **CONFIGS[name])
+    out = hydragen_attention_nopad(q, k, v, sks, svs, seq_len=lens)
+    B = q.shape[0]
+    idx = torch.tensor(sorted({0, 1, B // 3, B // 2, B - 2, B - 1}), device=DEV)
+    f = lambda t: t.float().cpu().numpy()
+    lv_k = [f(sk[idx // (B // sk.shape[0])]) for sk in sks]   # each picked sequence becomes its own group
+    lv_v = [f(sv[idx // (B // sv.shape[0])]) for sv in svs]
+    want = O.hydragen_attention_nopad(f(q[idx]), f(k[idx]), f(v[idx]), lv_k, lv_v, lens[idx].cpu().numpy().astype(np.int32))
+    assert_close(f(out[idx]), want, dt, name + " vs float64 oracle")
+
+
 @pytest.mark.parametrize("dt", ["bf16"])
 def test_c2_decomposed_equals_nosharing_kernel(dt):
     """Full C2 batch: Hydragen path vs the no-sharing path (every sequence owns [P+S] private keys),

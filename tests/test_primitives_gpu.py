@@ -64,11 +64,12 @@ def test_flash_attention_varlen(dt):
 
     rng = np.random.default_rng(5)
     hq, hkv, D = 8, 2, 128
-    qlens, klens = [3, 1, 7, 140], [9, 130, 1, 64]
-    cu_q = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
-    cu_k = np.concatenate([[0], np.cumsum(klens)]).astype(np.int32)
-    q, k, v = _rand(rng, (cu_q[-1], hq, D), dt), _rand(rng, (cu_k[-1], hkv, D), dt), _rand(rng, (cu_k[-1], hkv, D), dt)
-    for causal in (False,):
+    for causal in (False, True):
+        # causal = bottom-right aligned (flash.py:336-349 passes it through): every query must keep at least one key
+        qlens, klens = ([3, 1, 7, 140], [9, 130, 1, 64]) if not causal else ([3, 1, 7, 140], [9, 130, 7, 200])
+        cu_q = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
+        cu_k = np.concatenate([[0], np.cumsum(klens)]).astype(np.int32)
+        q, k, v = _rand(rng, (cu_q[-1], hq, D), dt), _rand(rng, (cu_k[-1], hkv, D), dt), _rand(rng, (cu_k[-1], hkv, D), dt)
         out, lse = flash_attention_varlen(dev(q, dt), dev(k, dt), dev(v, dt), dev(cu_q), dev(cu_k),
                                           max(qlens), max(klens), causal=causal)
         torch.cuda.synchronize()
@@ -135,3 +136,102 @@ def test_prefix_only_early_exit():
     torch.cuda.synchronize()
     want = O.hydragen_attention_nopad(q, np.zeros((B, 0, hkv, D)), np.zeros((B, 0, hkv, D)), [sk], [sv])
     assert_close(out.float().cpu().numpy(), want, dt, "prefix only")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("B,P", [(4, 1024), (2, 700), (16, 513)])
+def test_prefix_only_early_exit_with_split_kv(dt, B, P):
+    """the early exit of attention.py:273-274 on shapes whose prefix pass splits the keys (few units, long
+    prefix) -- the workspace query and the launch must agree."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    rng = np.random.default_rng(B * 1000 + P)
+    hq, hkv, D = 8, 8, 128
+    q = _rand(rng, (B, 1, hq, D), dt)
+    sk, sv = _rand(rng, (1, P, hkv, D), dt), _rand(rng, (1, P, hkv, D), dt)
+    k = torch.empty(B, 0, hkv, D, dtype=dev(q, dt).dtype, device="cuda:0")
+    out = hydragen_attention_nopad(dev(q, dt), k, k.clone(), [dev(sk, dt)], [dev(sv, dt)])
+    torch.cuda.synchronize()
+    want = O.hydragen_attention_nopad(q, np.zeros((B, 0, hkv, D)), np.zeros((B, 0, hkv, D)), [sk], [sv])
+    assert_close(out.float().cpu().numpy(), want, dt, "prefix only, split-KV")
+
+
+def test_deep_hierarchy_of_long_levels_single_kv_head():
+    """three long shared levels with one kv head (the TP=8 70B shard's head layout): every level wants the
+    maximum split; together they must still fit the epilogue's merge budget and give the oracle's answer."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    dt, rng = "bf16", np.random.default_rng(77)
+    B, hq, hkv, D, n = 16, 8, 1, 128, 8192
+    q = _rand(rng, (B, 1, hq, D), dt)
+    k, v = _rand(rng, (B, 5, hkv, D), dt), _rand(rng, (B, 5, hkv, D), dt)
+    sks = [_rand(rng, (sb, n, hkv, D), dt) for sb in (1, 2, 4)]
+    svs = [_rand(rng, (sb, n, hkv, D), dt) for sb in (1, 2, 4)]
+    lens = np.asarray([5, 1, 3, 2] * 4, dtype=np.int32)
+    out = hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(x, dt) for x in sks],
+                                   [dev(x, dt) for x in svs], dev(lens))
+    torch.cuda.synchronize()
+    want = O.hydragen_attention_nopad(q, k, v, sks, svs, lens)
+    assert_close(out.float().cpu().numpy(), want, dt, "3 long levels, 1 kv head")
+
+
+@pytest.mark.parametrize("levels", [[(1, 300)], [(1, 200), (4, 40)], [(1, 4096)]])
+def test_decode_phases_equal_the_one_call_form(levels):
+    """HYD_PHASE_SHARED followed by HYD_PHASE_UNIQUE (what bench.py issues to put an event between the two kernels)
+    is bit-identical to HYD_PHASE_ALL."""
+    import ctypes as C
+    from hydragen_amd import _lib
+    from hydragen_amd._lib import DecodeParams
+    from hydragen_amd.attention import _fill_level
+    from hydragen_amd.flash import fill_suffix_params
+
+    dt, rng = "bf16", np.random.default_rng(len(levels) * 31 + levels[0][1])
+    B, hq, hkv, D, S = 8, 8, 2, 128, 12
+    q = dev(_rand(rng, (B, 1, hq, D), dt), dt)
+    k, v = dev(_rand(rng, (B, S, hkv, D), dt), dt), dev(_rand(rng, (B, S, hkv, D), dt), dt)
+    sks = [dev(_rand(rng, (sb, n, hkv, D), dt), dt) for sb, n in levels]
+    svs = [dev(_rand(rng, (sb, n, hkv, D), dt), dt) for sb, n in levels]
+    lens = dev(np.asarray([12, 1, 5, 7, 12, 3, 9, 2], dtype=np.int32))
+    lib = _lib.load()
+    outs = []
+    for phases in ((0,), (1, 2)):
+        out = torch.zeros_like(q)
+        ps = []
+        for ph in phases:
+            p = DecodeParams()
+            fill_suffix_params(p.suffix, q, k, v, lens, out)
+            p.n_levels, p.phase = len(levels), ph
+            for i, (sk, sv) in enumerate(zip(sks, svs)):
+                _fill_level(p.levels[i], sk, sv, None, None, False, B)
+            ps.append(p)
+        nbytes = lib.hyd_decode_workspace_bytes(C.byref(ps[0]))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda:0")
+        for p in ps:
+            p.workspace, p.workspace_bytes = ws.data_ptr(), nbytes
+            _lib.check(lib.hyd_decode_attn_fused(C.byref(p), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].abs().sum().item() > 0
+
+
+def test_misaligned_views_are_accepted():
+    """a contiguous tensor at a storage offset that is not a multiple of 16 bytes (the reference takes any
+    view) is copied to aligned memory instead of being refused."""
+    from hydragen_amd.flash import flash_attention_seqlen
+
+    dt, rng = "f16", np.random.default_rng(3)
+    B, S, H, D = 3, 9, 4, 64
+    q, k, v = _rand(rng, (B, 1, H, D), dt), _rand(rng, (B, S, H, D), dt), _rand(rng, (B, S, H, D), dt)
+
+    def off(x):
+        flat = torch.empty(x.size + 4, dtype=torch.float16, device="cuda:0")
+        flat[4:] = dev(x, dt).reshape(-1)
+        t = flat[4:].view(x.shape)
+        assert t.data_ptr() % 16 != 0 and t.is_contiguous()
+        return t
+
+    out, _ = flash_attention_seqlen(off(q), off(k), off(v), seq_len=None)
+    torch.cuda.synchronize()
+    want, _ = O.flash_attention_seqlen(q, k, v, None)
+    assert_close(out.float().cpu().numpy(), want, dt, "misaligned views")

@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """Turn a profiles/<tag>_pmc.txt table (tools/profile_round.sh) into profiles/traffic_latest.json, the per-launch
-HBM traffic bench.py reports as roofline.traffic.  FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B,
-MI355X_MICROARCH.md HBM section); both counters are in KB."""
+HBM traffic bench.py reports as roofline.traffic -- only for the command line the counters were collected with
+(steps, warm-up and shape are recorded here and compared by bench.py).  FETCH_SIZE is doubled (gfx950 counts 128-B
+requests as 64 B, MI355X_MICROARCH.md HBM section); both counters are in KB."""
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
-def main(path, tag):
+def main(path, tag, steps, warmup):
+    from bench import suffix_schedule
+
+    B, P, S, Hq, Hkv, D, e = 1024, 2048, 128, 32, 32, 128, 2
     vals = {}
     for line in open(path):
         parts = line.split()
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if c in parts:
                 i = parts.index(c)
-                kern = "suffix" if "suffix_attn_kernel" in line else "prefix" if "prefix_attn" in line else None
+                kern = "suffix" if "suffix_attn" in line else "prefix" if "prefix_attn" in line else None
                 if kern:
                     vals[(kern, c)] = float(parts[i + 2])
+    launches = suffix_schedule(max(warmup, 1), S)[:warmup] + suffix_schedule(steps, S)
+    suf_alg = sum(2 * e * Hkv * D * B * s + 2 * B * Hq * D * e + 4 * B * Hq for s in launches) / len(launches)
+    pre_alg = 2 * P * Hkv * D * e + 2 * B * Hq * D * e + 4 * B * Hq
     out = {
         "source": f"profiles/{tag}_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py "
-        "--steps 128 --warmup 0 --no-cpu-baseline --no-nosharing`; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md",
+        f"--steps {steps} --warmup {warmup}` (untimed legs off); per-launch mean over the {warmup} warm-up + {steps} timed "
+        "launches; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md",
+        "steps": steps, "warmup": warmup, "batch": B, "prefix": P, "max_suffix": S, "qheads": Hq, "kvheads": Hkv,
+        "suffix_algorithmic_bytes_per_launch": suf_alg, "prefix_algorithmic_bytes_per_launch": pre_alg,
     }
     for k in ("suffix", "prefix"):
         f, w = vals.get((k, "FETCH_SIZE")), vals.get((k, "WRITE_SIZE"))
@@ -30,4 +43,4 @@ def main(path, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))

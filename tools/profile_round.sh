@@ -1,31 +1,35 @@
 #!/bin/bash
 # Collect the per-round rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01_v4
+#   tools/profile_round.sh r02_v1 [steps] [warmup]
 # writes gpurun_out/<tag>_{kernel_stats,pmc}.txt, gpurun_out/<tag>_bench.json and gpurun_out/traffic_latest.json;
 # copy them into profiles/ afterwards.  Counter passes are separate runs with --pmc only (no trace domains).
+# The profiled command is the driver's bench command (same --steps/--warmup, hence the same suffix schedule) with the
+# legs outside the timed region switched off.
 set -u
-TAG=${1:-r01_vX}
+TAG=${1:-r02_vX}
+STEPS=${2:-20}
+WARM=${3:-5}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 128 --warmup 0 --no-cpu-baseline --no-nosharing"
+CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-protocol --no-model --no-accuracy"
 cd /tmp
 rm -rf /tmp/prof_*
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o run -- $CMD > $OUT/${TAG}_bench_profiled.json 2>/tmp/prof_stats.log
 DB=$(find /tmp/prof_stats -name '*.db' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- $CMD"; python $REPO/tools/rocprof_summary.py stats $DB; } > $OUT/${TAG}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- $CMD"; echo "# (averages are over the $WARM warm-up + $STEPS timed launches; both follow bench.py's uniform suffix schedule)"; python $REPO/tools/rocprof_summary.py stats $DB; } > $OUT/${TAG}_kernel_stats.txt
 {
-echo "# rocprofv3 --pmc passes (separate runs of the same command). FETCH_SIZE/WRITE_SIZE in KB per launch; gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)"
+echo "# rocprofv3 --pmc passes (separate runs of: $CMD). FETCH_SIZE/WRITE_SIZE in KB per launch; gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)"
 for C in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY"; do
   D=/tmp/prof_pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C -d $D -o run -- $CMD > /dev/null 2>$D.log
   DB=$(find $D -name '*.db' | head -1)
-  if [ -n "$DB" ]; then python $REPO/tools/rocprof_summary.py pmc $DB _attn_; else echo "# pass '$C' produced no db: $(tail -2 $D.log | tr '\n' ' ')"; fi
+  if [ -n "$DB" ]; then python $REPO/tools/rocprof_summary.py pmc $DB _attn; else echo "# pass '$C' produced no db: $(tail -2 $D.log | tr '\n' ' ')"; fi
 done
 } > $OUT/${TAG}_pmc.txt
-python $REPO/tools/make_traffic.py $OUT/${TAG}_pmc.txt $TAG > $OUT/traffic_latest.json
+python $REPO/tools/make_traffic.py $OUT/${TAG}_pmc.txt $TAG $STEPS $WARM > $OUT/traffic_latest.json
 cd $REPO
 cp $OUT/traffic_latest.json $REPO/profiles/traffic_latest.json
-python bench.py > $OUT/${TAG}_bench.json 2>/dev/null
-tail -c 1500 $OUT/${TAG}_bench.json
+python bench.py --steps $STEPS --warmup $WARM > $OUT/${TAG}_bench.json 2>$OUT/${TAG}_bench.err
+tail -c 2500 $OUT/${TAG}_bench.json
