@@ -77,7 +77,7 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMa
         // K/V staging per flop and no cross-half merge.
         const int force_rows = dev_switch("HYD_PREFIX_ROWS");  // 0 in product builds
         const int64_t units128 = (int64_t)p->sb * p->Hkv * pl->row_blocks;
-        const bool can = p->D == 128;
+        const bool can = true;
         if (can && (force_rows == 256 || (force_rows == 0 && units128 > kNumCU))) {
             pl->wg_rows = 256;
             pl->row_blocks = (int)((mrows + 255) / 256);
@@ -150,7 +150,10 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
 // Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
 // `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
 int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
-    return launch_prefix_pl(a, dtype, D, causal, grid, s);
+#ifdef HYD_ABLATION_BUILD
+    if (dev_switch("HYD_PREFIX_PL")) return launch_prefix_pl(a, dtype, D, causal, grid, s);  // round-1 kernel, A/B only
+#endif
+    return launch_prefix_w64(a, dtype, D, causal, grid, s);
 }
 
 int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s) {

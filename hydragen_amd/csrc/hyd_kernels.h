@@ -82,7 +82,8 @@ struct RopeArgs {
 };
 
 // launchers (defined next to the kernels); return hipError_t as int
-int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
+int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);   // ablation builds only
+int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
 int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape);

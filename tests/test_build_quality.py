@@ -13,7 +13,7 @@ CSRC = Path(__file__).resolve().parent.parent / "hydragen_amd" / "csrc"
 HIPCC = "/opt/rocm/bin/hipcc"
 # file -> (max VGPRs per kernel matching the regex)
 LIMITS = {
-    "prefix_attn_pl.hip": [(r"prefix_attn_pl_kernel", 256)],   # 2 waves / SIMD
+    "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512)],   # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs)
     "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 128)],  # 4 waves / SIMD
     "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1E", 80)],  # MHA decode: 6 waves / SIMD
     "combine.hip": [(r"combine", 128)],
@@ -46,3 +46,25 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy():
             for pat, lim in LIMITS[src]:
                 if re.search(pat, k["name"]):
                     assert k["vgpr"] <= lim, f"{src}: {k['name']} uses {k['vgpr']} VGPRs (> {lim})"
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_prefix_kernel_owns_its_accumulator_registers():
+    """prefix_attn_w64.hip keeps the O accumulators and the Q fragments in literal AGPRs (a[0:191]) that only its own
+    inline-asm statements name.  That is safe only while hipcc itself never touches an AGPR in those kernels (it would,
+    for spills): no instruction outside ;;#ASMSTART / ;;#ASMEND may name one, and every kernel must allocate >= 160."""
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                          str(CSRC / "prefix_attn_w64.hip"), "-o", "-"], capture_output=True, text=True, check=True).stdout
+    inasm, bad = False, []
+    for line in out.splitlines():
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
+        elif not inasm and t and not t.startswith((";", ".", "//")) and re.search(r"\ba\[?\d", t.split(";")[0]):
+            bad.append(t)
+    assert not bad, bad[:5]
+    counts = [int(x) for x in re.findall(r"\.agpr_count:\s+(\d+)", out)]
+    assert counts and min(counts) >= 160, counts
+    assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and "a[128:131]" in out

@@ -1,4 +1,6 @@
 """-m gpu: the attention primitives (reference flash.py signatures) against the float64 oracle."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -27,7 +29,7 @@ def _rand(rng, shape, dt):
 def test_flash_attention(dt, D, b, sq, sk, hq, hkv, causal):
     from hydragen_amd.flash import flash_attention
 
-    rng = np.random.default_rng(hash((dt, D, b, sq, sk, hq, hkv, causal)) % 2**32)
+    rng = np.random.default_rng(zlib.crc32(repr((dt, D, b, sq, sk, hq, hkv, causal)).encode()))
     q, k, v = _rand(rng, (b, sq, hq, D), dt), _rand(rng, (b, sk, hkv, D), dt), _rand(rng, (b, sk, hkv, D), dt)
     out, lse = flash_attention(dev(q, dt), dev(k, dt), dev(v, dt), causal=causal)
     torch.cuda.synchronize()
@@ -90,7 +92,7 @@ def test_flash_attention_varlen(dt):
 def test_flash_attention_seqlen(dt, D, b, nq, mk, hq, hkv, lens):
     from hydragen_amd.flash import flash_attention_seqlen
 
-    rng = np.random.default_rng(hash((dt, D, b, nq, mk)) % 2**32)
+    rng = np.random.default_rng(zlib.crc32(repr((dt, D, b, nq, mk)).encode()))
     q, k, v = _rand(rng, (b, nq, hq, D), dt), _rand(rng, (b, mk, hkv, D), dt), _rand(rng, (b, mk, hkv, D), dt)
     sl = np.asarray(lens, dtype=np.int32)
     out, lse = flash_attention_seqlen(dev(q, dt), dev(k, dt), dev(v, dt), seq_len=dev(sl))
