@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--model-new-tokens", type=int, default=128)
+    ap.add_argument("--no-xgmi", action="store_true", help="N > 1: skip the direct xGMI all-reduce (hyd_allreduce_sum) leg")
     ap.add_argument("--no-graph-collective", action="store_true",
                     help="N > 1: skip the HIP-graph capture of (attention + all-reduce), llama.py:849-854")
     return ap.parse_args()
@@ -296,6 +297,8 @@ def main():
         res["allreduce_bytes"] = ar_buf.numel() * 2
         res["rccl_ranks"] = dist.get_world_size()
         res["collective_backend"] = backend
+        if not args.no_xgmi:
+            res["allreduce_xgmi"] = _guarded(lambda: xgmi_allreduce_leg(ar_buf), 120.0, res, rank, key="allreduce_xgmi")
         if backend == "nccl" and not args.no_graph_collective:
             res["graph_collective"] = _guarded(lambda: graph_collective(ops, sweep[len(sweep) // 2], ar_buf), 120.0,
                                                res, rank)
@@ -331,7 +334,7 @@ def _attach_traffic(suffix_roof, prefix_roof, args, world):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes, only when they were collected with THIS
     command line (same shape and the same suffix schedule); otherwise only the measured traffic / algorithmic ratio."""
     tr = REPO / "profiles" / "traffic_latest.json"
-    if not tr.exists():
+    if not tr.exists() or world != 1:  # the counters were collected on the single-GPU shape
         return
     t = json.loads(tr.read_text())
     same = (world == 1 and t.get("steps") == args.steps and t.get("batch") == args.batch and t.get("prefix") == args.prefix
@@ -347,10 +350,10 @@ def _attach_traffic(suffix_roof, prefix_roof, args, world):
             roof["traffic_over_algorithmic"] = b / t[f"{key}_algorithmic_bytes_per_launch"]
 
 
-def _guarded(fn, seconds, res, rank):
+def _guarded(fn, seconds, res, rank, key="graph_collective"):
     """Run an optional leg; if it hangs (a collective that never completes), print the line without it and leave."""
     def bail():
-        res["graph_collective"] = {"error": f"timed out after {seconds:.0f} s"}
+        res[key] = {"error": f"timed out after {seconds:.0f} s"}
         if rank == 0:
             print(json.dumps(res))
             sys.stdout.flush()
@@ -402,6 +405,37 @@ def _timed_replays(graph, iters, flush):
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) * 1e3)
     return out
+
+
+def xgmi_allreduce_leg(ar_buf):
+    """N > 1: the same [B, 1, hidden] tensor through the library's two-shot direct all-reduce over IPC-mapped peer
+    blocks (hyd_allreduce_sum) -- result checked against RCCL's, then timed with HIP events."""
+    from hydragen_amd.xgmi_allreduce import XgmiAllReduce
+
+    comm = XgmiAllReduce(max_bytes=ar_buf.numel() * ar_buf.element_size())
+    x = torch.randn_like(ar_buf)
+    want = x.clone()
+    dist.all_reduce(want)
+    got = comm.all_reduce_(x.clone())
+    torch.cuda.synchronize()
+    err = float((got.float() - want.float()).abs().max())
+    for _ in range(5):
+        comm.all_reduce_(x)
+    torch.cuda.synchronize()
+    dist.barrier()
+    us = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        comm.all_reduce_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3)
+    st = comm.status()
+    dist.barrier()
+    comm.close()
+    return {**_stats(us), "bytes": ar_buf.numel() * ar_buf.element_size(), "max_abs_diff_vs_rccl": err, "status": st,
+            "what": "hyd_allreduce_sum: stage + two-shot direct exchange, eager, back to back"}
 
 
 def graph_collective(ops, s, ar_buf):

@@ -83,6 +83,14 @@ class RopeParams(C.Structure):
     ]
 
 
+class AllReduceParams(C.Structure):
+    _fields_ = [
+        ("blocks", C.POINTER(C.c_void_p)), ("in_", C.c_void_p), ("out", C.c_void_p), ("count", C.c_int64),
+        ("max_bytes", C.c_size_t), ("dtype", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 # every symbol include/hydragen_hip.h declares
 EXPORTS = {
     "hyd_version": (C.c_int, []),
@@ -96,6 +104,12 @@ EXPORTS = {
     "hyd_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeParams)]),
     "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
     "hyd_rope_append_decode": (C.c_int, [C.POINTER(RopeParams), C.c_void_p]),
+    "hyd_ipc_get_handle": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hyd_ipc_open_handle": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hyd_ipc_close_handle": (C.c_int, [C.c_void_p]),
+    "hyd_allreduce_block_bytes": (C.c_size_t, [C.c_int32, C.c_size_t]),
+    "hyd_allreduce_sum": (C.c_int, [C.POINTER(AllReduceParams), C.c_void_p]),
+    "hyd_allreduce_status": (C.c_void_p, [C.c_void_p]),
     "hyd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

@@ -466,6 +466,66 @@ int hyd_rope_append_decode(const hyd_rope_params* p, void* stream) {
 // attention.py:273-274: a single shared level and no unique keys -> the prefix result IS the answer
 static bool decode_is_prefix_only(const hyd_decode_params* p) { return p->n_levels == 1 && p->suffix.kv_len == 0; }
 
+int hyd_ipc_get_handle(const void* dev_ptr, void* handle_out) {
+    static_assert(sizeof(hipIpcMemHandle_t) == HYD_IPC_HANDLE_BYTES, "IPC handle size");
+    if (!dev_ptr || !handle_out) return fail(HYD_ERR_BAD_ARG, "null pointer");
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, const_cast<void*>(dev_ptr));
+    if (e != hipSuccess) return fail(HYD_ERR_LAUNCH, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    memcpy(handle_out, &h, sizeof(h));
+    return HYD_OK;
+}
+
+int hyd_ipc_open_handle(const void* handle, void** dev_ptr_out) {
+    if (!handle || !dev_ptr_out) return fail(HYD_ERR_BAD_ARG, "null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    const hipError_t e = hipIpcOpenMemHandle(dev_ptr_out, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(HYD_ERR_LAUNCH, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    return HYD_OK;
+}
+
+int hyd_ipc_close_handle(void* dev_ptr) {
+    if (!dev_ptr) return fail(HYD_ERR_BAD_ARG, "null pointer");
+    const hipError_t e = hipIpcCloseMemHandle(dev_ptr);
+    return e == hipSuccess ? HYD_OK : fail(HYD_ERR_LAUNCH, "hipIpcCloseMemHandle: %s", hipGetErrorString(e));
+}
+
+size_t hyd_allreduce_block_bytes(int32_t world, size_t max_bytes) {
+    if (world < 1 || world > HYD_ALLREDUCE_MAX_WORLD || max_bytes == 0) return 0;
+    return allreduce_block_bytes(world, max_bytes);
+}
+
+const uint32_t* hyd_allreduce_status(const void* own_block) {
+    // layout of allreduce.hip: 2 x 8 flags of 32 words, then the local words {epoch, arrivals, status}
+    return own_block ? static_cast<const uint32_t*>(own_block) + 2 * HYD_ALLREDUCE_MAX_WORLD * 32 + 2 : nullptr;
+}
+
+int hyd_allreduce_sum(const hyd_allreduce_params* p, void* stream) {
+    if (!p || !p->blocks) return fail(HYD_ERR_BAD_ARG, "null params");
+    if (p->world < 1 || p->world > HYD_ALLREDUCE_MAX_WORLD) return fail(HYD_ERR_UNSUPPORTED, "world %d (1..%d)", p->world, HYD_ALLREDUCE_MAX_WORLD);
+    if (p->rank < 0 || p->rank >= p->world) return fail(HYD_ERR_BAD_ARG, "rank %d of %d", p->rank, p->world);
+    if (p->dtype != HYD_F16 && p->dtype != HYD_BF16 && p->dtype != HYD_F32) return fail(HYD_ERR_UNSUPPORTED, "dtype %d", p->dtype);
+    if (p->count < 0) return fail(HYD_ERR_BAD_ARG, "count %lld", (long long)p->count);
+    if (p->count == 0) return HYD_OK;
+    const size_t bytes = (size_t)p->count * (p->dtype == HYD_F32 ? 4 : 2);
+    if (bytes > p->max_bytes) return fail(HYD_ERR_WORKSPACE, "%zu bytes exceed the blocks' max_bytes %zu", bytes, p->max_bytes);
+    int rc;
+    if ((rc = check_ptr_align(p->in, "in")) || (rc = check_ptr_align(p->out, "out"))) return rc;
+    char* blocks[HYD_ALLREDUCE_MAX_WORLD];
+    for (int i = 0; i < p->world; ++i) {
+        if ((rc = check_ptr_align(p->blocks[i], "block"))) return rc;
+        blocks[i] = static_cast<char*>(p->blocks[i]);
+    }
+    if (p->world == 1) {
+        if (p->in != p->out) (void)hipMemcpyAsync(p->out, p->in, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+        return HYD_OK;
+    }
+    rc = launch_allreduce(blocks, allreduce_block_bytes(p->world, p->max_bytes), p->in, p->out, p->count, p->dtype, p->rank,
+                          p->world, p->max_bytes, static_cast<hipStream_t>(stream));
+    return rc ? fail(HYD_ERR_LAUNCH, "all-reduce kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
 size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {
     if (!p || p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return 0;
     if (decode_is_prefix_only(p)) {

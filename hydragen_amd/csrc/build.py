@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-SOURCES = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip"]
+SOURCES = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
 HEADERS = ["hyd_common.h", "hyd_kernels.h", "../../include/hydragen_hip.h"]
 LIB = HERE / "libhydragen_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -89,5 +89,8 @@ int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape);
 int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 int launch_combine(const CombineArgs& a, hipStream_t s);
+size_t allreduce_block_bytes(int world, size_t max_bytes);
+int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, void* out, int64_t count, int dtype,
+                     int rank, int world, size_t max_bytes, hipStream_t s);
 
 }  // namespace hyd

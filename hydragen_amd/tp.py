@@ -55,10 +55,24 @@ def shard_o_proj_weight(w: Tensor, rank=None, world_size=None) -> Tensor:
     return w[:, sl].contiguous()
 
 
+_xgmi = None  # optional hydragen_amd.xgmi_allreduce.XgmiAllReduce
+
+
+def use_xgmi_allreduce(comm) -> None:
+    """Route `all_reduce_sum` through the direct xGMI all-reduce (`hyd_allreduce_sum`) instead of RCCL for tensors that
+    fit its blocks; `None` switches back."""
+    global _xgmi
+    _xgmi = comm
+
+
 def all_reduce_sum(x: Tensor) -> Tensor:
     """The forward hook of tp.py:108-112 / 83-87.  In place; no-op without a process group."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        if _xgmi is not None and x.is_cuda and x.is_contiguous() and x.numel() * x.element_size() <= _xgmi.max_bytes \
+                and x.dtype in (torch.float16, torch.bfloat16, torch.float32):
+            _xgmi.all_reduce_(x)
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
     return x
 
 

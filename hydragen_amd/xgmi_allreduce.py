@@ -1,0 +1,110 @@
+"""
+Host side of `hyd_allreduce_sum` (include/hydragen_hip.h): the all-reduce(sum) behind the row-parallel o_proj /
+down_proj of /root/reference/hydragen/tp.py:83-87,108-112 as a two-shot direct exchange over peer-mapped device
+memory (xGMI), instead of a RCCL ring.  One process per GPU; `torch.distributed` (any backend) is used once, to
+exchange the IPC handles of the per-rank shared blocks.
+
+    comm = XgmiAllReduce(max_bytes=32 << 20)      # after init_process_group; collective
+    comm.all_reduce_(x)                           # in place, on torch's current stream; HIP-graph capturable
+    hydragen_amd.tp.use_xgmi_allreduce(comm)      # route tp.all_reduce_sum through it
+
+The shared block is a raw hipMalloc allocation (hipIpcGetMemHandle needs an allocation base, which a tensor of the
+caching allocator is not); it is released in `close()`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from . import _lib
+from ._lib import HYD_BF16, HYD_F16, HYD_F32, AllReduceParams
+
+_DT = {torch.float16: HYD_F16, torch.bfloat16: HYD_BF16, torch.float32: HYD_F32}
+_hip = None
+
+
+def _runtime():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")  # the runtime torch already mapped
+        _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip.hipFree.argtypes = [C.c_void_p]
+        _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hip
+
+
+class XgmiAllReduce:
+    def __init__(self, max_bytes: int, group=None, device: torch.device | None = None):
+        assert dist.is_initialized(), "init_process_group first: the IPC handles are exchanged through it"
+        self.lib = _lib.load()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise NotImplementedError("one node: at most 8 ranks")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.max_bytes = int(max_bytes)
+        self.block_bytes = self.lib.hyd_allreduce_block_bytes(self.world, self.max_bytes)
+        assert self.block_bytes > 0
+        hip = _runtime()
+        with torch.cuda.device(self.device):
+            own = C.c_void_p()
+            if hip.hipMalloc(C.byref(own), self.block_bytes) != 0:
+                raise RuntimeError("hipMalloc of the all-reduce block failed")
+            hip.hipMemset(own, 0, self.block_bytes)
+            torch.cuda.synchronize()
+            handle = (C.c_ubyte * 64)()
+            _lib.check(self.lib.hyd_ipc_get_handle(own, handle))
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle), group=group)
+            self._own = own
+            self._opened = []
+            ptrs = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs.append(own.value)
+                    continue
+                p = C.c_void_p()
+                buf = (C.c_ubyte * 64).from_buffer_copy(h)
+                _lib.check(self.lib.hyd_ipc_open_handle(buf, C.byref(p)))
+                self._opened.append(p)
+                ptrs.append(p.value)
+            self._blocks = (C.c_void_p * self.world)(*ptrs)
+        dist.barrier(group=group)  # every block is mapped everywhere before the first call
+
+    def all_reduce_(self, x: Tensor) -> Tensor:
+        """In-place sum over the ranks; x: contiguous fp16 / bf16 / fp32 CUDA tensor of at most max_bytes."""
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError("all_reduce_ takes a contiguous CUDA tensor")
+        p = AllReduceParams()
+        p.blocks = C.cast(self._blocks, C.POINTER(C.c_void_p))
+        p.in_, p.out, p.count = x.data_ptr(), x.data_ptr(), x.numel()
+        p.max_bytes, p.dtype, p.rank, p.world = self.max_bytes, _DT[x.dtype], self.rank, self.world
+        _lib.check(self.lib.hyd_allreduce_sum(C.byref(p), torch.cuda.current_stream().cuda_stream))
+        return x
+
+    def status(self) -> int:
+        """0 = every call so far completed; 1 / 2 = a peer did not show up in shot 1 / 2 (synchronises)."""
+        torch.cuda.synchronize()
+        word = C.c_uint32()
+        _runtime().hipMemcpy(C.byref(word), self.lib.hyd_allreduce_status(self._own), 4, 2)  # device -> host
+        return int(word.value)
+
+    def close(self):
+        if getattr(self, "_own", None) is None:
+            return
+        torch.cuda.synchronize()
+        for p in self._opened:
+            self.lib.hyd_ipc_close_handle(p)
+        _runtime().hipFree(self._own)
+        self._own, self._opened = None, []
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

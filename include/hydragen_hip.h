@@ -204,6 +204,44 @@ typedef struct hyd_rope_params {
 
 HYD_API int hyd_rope_append_decode(const hyd_rope_params* p, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * All-reduce(sum) of the tensor-parallel block output (hydragen/tp.py:83-87 after down_proj, :108-112 after
+ * o_proj; the reference calls torch.distributed / NCCL there) as a two-shot direct exchange over
+ * peer-mapped device memory: xGMI is a full mesh, so every rank reads its slice straight from every
+ * peer (reduce-scatter), then every reduced slice from its owner (all-gather).  One process per GPU.
+ *
+ * Each rank owns one zero-initialised "shared block" of hyd_allreduce_block_bytes() bytes in device
+ * memory obtained from hipMalloc, exports it with hyd_ipc_get_handle, and maps every peer's block with
+ * hyd_ipc_open_handle (handles travel over any host channel, e.g. torch.distributed all_gather_object).
+ * `blocks` is a HOST array of `world` device pointers: blocks[r] is rank r's block as mapped in THIS
+ * process (blocks[rank] is the own block).  `in` / `out` are ordinary device buffers, 16-byte aligned,
+ * count * sizeof(dtype) <= max_bytes; in == out is allowed.  Every rank must issue the same sequence of
+ * calls.  Capture-safe: the call's epoch lives in the block, not in the arguments.  A peer that does
+ * not show up within ~1 s makes the kernel give up (status word != 0, see hyd_allreduce_status) instead
+ * of hanging the device.
+ * ------------------------------------------------------------------------------------------ */
+#define HYD_IPC_HANDLE_BYTES 64
+#define HYD_ALLREDUCE_MAX_WORLD 8
+HYD_API int hyd_ipc_get_handle(const void* dev_ptr, void* handle_out);
+HYD_API int hyd_ipc_open_handle(const void* handle, void** dev_ptr_out);
+HYD_API int hyd_ipc_close_handle(void* dev_ptr);
+
+typedef struct hyd_allreduce_params {
+    void* const* blocks;  /* HOST array [world] of device pointers (see above)                      */
+    const void* in;
+    void* out;
+    int64_t count;        /* elements                                                              */
+    size_t max_bytes;     /* the value the blocks were sized with                                  */
+    int32_t dtype;        /* HYD_F16 | HYD_BF16 | HYD_F32; accumulation in fp32                    */
+    int32_t rank, world;  /* world <= HYD_ALLREDUCE_MAX_WORLD                                      */
+    int32_t reserved;
+} hyd_allreduce_params;
+
+HYD_API size_t hyd_allreduce_block_bytes(int32_t world, size_t max_bytes);
+HYD_API int hyd_allreduce_sum(const hyd_allreduce_params* p, void* stream);
+/* Device pointer of the status word inside a block (uint32: 0 = ok, 1 / 2 = a peer timed out in shot 1 / 2). */
+HYD_API const uint32_t* hyd_allreduce_status(const void* own_block);
+
 HYD_API int hyd_version(void);
 HYD_API const char* hyd_last_error_string(void);
 

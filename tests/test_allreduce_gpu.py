@@ -1,0 +1,90 @@
+"""-m gpu: the direct xGMI all-reduce (`hyd_allreduce_sum`, replaces the NCCL all-reduce of
+/root/reference/hydragen/tp.py:83-87,108-112) with TWO processes sharing the one GPU of the box: each rank maps the
+other's block through hipIpc handles exactly as it would across two GPUs, so the protocol (staging, epochs, flags,
+system-scope fences, slice ownership, tails, repeated calls, graph replay) is exercised end to end; only the link
+bandwidth needs a multi-GPU node.  Reference: the sum of the ranks' inputs computed on the host."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        from hydragen_amd.xgmi_allreduce import XgmiAllReduce
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = XgmiAllReduce(max_bytes=9 << 20)
+        worst = 0.0
+        cases = [(torch.bfloat16, 1024 * 4096), (torch.float16, 4097), (torch.float32, 1000003), (torch.bfloat16, 8),
+                 (torch.bfloat16, 7), (torch.float16, 2 * 1024 * 1024 + 24)]
+        for rep in range(3):  # repeated calls: epochs, flag reuse, staging reuse
+            for dt, n in cases:
+                g = torch.Generator(device="cuda").manual_seed(100 * rep + n % 997 + rank)
+                x = torch.randn(n, device="cuda", dtype=dt, generator=g)
+                parts = [torch.empty(n, dtype=dt) for _ in range(world)]
+                dist.all_gather(parts, x.cpu())
+                want = sum(p.float() for p in parts)
+                comm.all_reduce_(x)
+                torch.cuda.synchronize()
+                tol = 1e-6 if dt == torch.float32 else (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -10)
+                err = ((x.float().cpu() - want).abs() / (want.abs() + 1.0)).max().item()
+                assert err <= tol * 2, (rank, rep, dt, n, err)
+                worst = max(worst, err)
+        assert comm.status() == 0
+        # HIP-graph capture + replay with changing inputs (llama.py:849-854 captures the all-reduce with the forward)
+        x = torch.zeros(1024, 1, 4096, device="cuda", dtype=torch.bfloat16)
+        src = torch.empty_like(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                x.copy_(src.normal_())
+                comm.all_reduce_(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        dist.barrier()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            x.copy_(src)
+            comm.all_reduce_(x)
+        for rep in range(3):
+            src.normal_(generator=torch.Generator(device="cuda").manual_seed(7 * rep + rank))
+            torch.cuda.synchronize()
+            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.cpu())
+            want = sum(p.float() for p in parts)
+            graph.replay()
+            torch.cuda.synchronize()
+            err = ((x.float().cpu() - want).abs() / (want.abs() + 1.0)).max().item()
+            assert err <= 2.0 ** -7, (rank, "graph", rep, err)
+        assert comm.status() == 0
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
+        ret.put((rank, "ok", worst))
+    except Exception as e:  # report instead of hanging the parent
+        import traceback
+        ret.put((rank, "fail", traceback.format_exc()))
+
+
+def test_xgmi_allreduce_two_ranks_on_one_gpu():
+    import torch.multiprocessing as mp
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [ret.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, state, info in res:
+        assert state == "ok", f"rank {rank}: {info}"

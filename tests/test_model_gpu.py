@@ -170,7 +170,7 @@ def test_hydragen_vs_nosharing_and_flat_hierarchy(dtype):
     assert rdiff(torch.stack(a), torch.stack(c)).mean() < bound
 
 
-def _tp_gpu_worker(rank, world, port, shard_dir, ids_cpu, overrides_cpu, ret):
+def _tp_gpu_worker(rank, world, port, shard_dir, ids_cpu, overrides_cpu, ret, xgmi=False):
     import os
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
@@ -180,6 +180,14 @@ def _tp_gpu_worker(rank, world, port, shard_dir, ids_cpu, overrides_cpu, ret):
     # both ranks share the one GPU of the test box; the collective goes through gloo (RCCL needs one GPU per rank)
     assert utils.maybe_init_dist(backend="gloo") == rank
     model = tp.from_pretrained_tp(shard_dir, device=DEV)
+    comm = None
+    if xgmi:
+        # the direct all-reduce over IPC-mapped peer blocks (hyd_allreduce_sum), captured INSIDE the decode graph like
+        # the reference's NCCL all-reduce (llama.py:849-854); gloo only carries the handle exchange
+        from hydragen_amd.xgmi_allreduce import XgmiAllReduce
+        comm = XgmiAllReduce(max_bytes=1 << 20)
+        tp.use_xgmi_allreduce(comm)
+        model.graph(True)
     ids = [x.to(DEV) for x in ids_cpu]
     B, new = overrides_cpu.shape
     model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=32,
@@ -188,11 +196,17 @@ def _tp_gpu_worker(rank, world, port, shard_dir, ids_cpu, overrides_cpu, ret):
                                  temperature=0.0, return_logits=True, token_overrides=overrides_cpu.to(DEV))
     if rank == 0:
         ret.put(torch.stack(logits).float().cpu().numpy())
+    if comm is not None:
+        assert comm.status() == 0
     dist.barrier()
+    if comm is not None:
+        tp.use_xgmi_allreduce(None)
+        comm.close()
     dist.destroy_process_group()
 
 
-def test_tensor_parallel_model_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("xgmi", [False, True])
+def test_tensor_parallel_model_two_ranks_on_one_gpu(tmp_path, xgmi):
     """head-sharded model shell (apply_tp shards, per-rank KV caches with Hkv/2 heads, the HIP
     operator on each rank's heads, all-reduce after o_proj and down_proj) reproduces the unsharded model's decode
     logits.  World size 2 on the single GPU of the box, gloo collectives."""
@@ -217,7 +231,7 @@ def test_tensor_parallel_model_two_ranks_on_one_gpu(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, 2, port, str(tmp_path), [x.cpu() for x in ids], overrides.cpu(), ret))
+    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, 2, port, str(tmp_path), [x.cpu() for x in ids], overrides.cpu(), ret, xgmi))
              for r in range(2)]
     for p in procs:
         p.start()
