@@ -48,6 +48,8 @@ struct SuffixArgs {
     int32_t units; // B * Hkv
     int32_t n_partials;
     float scale_log2e;
+    int32_t packed;  // shapes allow the lane-group path for short sequences (set by launch_suffix)
+    int32_t pad_;
     PartialDev partials[kMaxCombine];
 };
 

@@ -54,6 +54,195 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float (&acc)[8],
     m = mf;
 }
 
+// Epilogue of one output row (8 dims per lane, the D/8 lanes of a row call it together): normalise the suffix pass's
+// (m, l, acc), merge with the prefix partials (attention.py:21-43 semantics, N partials) and store.  Partial 0 may
+// already sit in registers (pre0: prefetched under the K/V stream).
+template <typename T, int D, int NBATCH = 4>
+__device__ __forceinline__ void finish_row(const SuffixArgs& a, int64_t ridx, int sub, float m, float l, const float (&acc)[8],
+                                           bool pre0, float l0, const u32x4& po0) {
+    using TR = Traits<T>;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const float lse_s = l > 0.f ? m * kLn2 + __logf(l) : -INFINITY;
+    if (a.lse && sub == 0) a.lse[ridx] = lse_s;
+    float num[8];
+    if (a.n_partials == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) num[j] = acc[j] * inv;
+    } else {
+        const int i0 = pre0 ? 1 : 0;  // partial 0 already sits in registers
+        // The remaining partials (split-KV slices, further levels) are read NBATCH at a time with clamped indices,
+        // so that a batch's loads are all in flight together instead of one memory latency per partial.
+        const int np = a.n_partials;
+        float M = pre0 ? fmaxf(lse_s, l0) : lse_s;
+        for (int i = i0; i < np; i += NBATCH) {
+            float lv[NBATCH];
+#pragma unroll
+            for (int j = 0; j < NBATCH; ++j) lv[j] = a.partials[min(i + j, np - 1)].lse[ridx];
+#pragma unroll
+            for (int j = 0; j < NBATCH; ++j) M = fmaxf(M, lv[j]);
+        }
+        const float Ms = (M == -INFINITY) ? 0.f : M;
+        const float ws = __expf(lse_s - Ms);
+        float den = ws;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) num[j] = acc[j] * (inv * ws);
+        if (pre0) {
+            const float w = __expf(l0 - Ms);
+            den += w;
+            float pv[8];
+            widen8<T>(po0, pv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
+        }
+        for (int i = i0; i < np;) {
+            // a batch = up to NBATCH consecutive partials of the same element type (slices of one level are adjacent)
+            const bool f32 = a.partials[i].is_f32 != 0;
+            int cnt = 1;
+            while (cnt < NBATCH && i + cnt < np && (a.partials[i + cnt].is_f32 != 0) == f32) ++cnt;
+            float lw[NBATCH];
+            float pv[NBATCH][8];
+            if (f32) {
+                f32x4 x0[NBATCH], x1[NBATCH];
+#pragma unroll
+                for (int j = 0; j < NBATCH; ++j) {
+                    const PartialDev& pd = a.partials[i + min(j, cnt - 1)];
+                    const float* po = static_cast<const float*>(pd.out) + ridx * D + sub * 8;
+                    lw[j] = pd.lse[ridx];
+                    x0[j] = *reinterpret_cast<const f32x4*>(po);
+                    x1[j] = *reinterpret_cast<const f32x4*>(po + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < NBATCH; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pv[j][e] = x0[j][e];
+                        pv[j][4 + e] = x1[j][e];
+                    }
+            } else {
+                u32x4 x[NBATCH];
+#pragma unroll
+                for (int j = 0; j < NBATCH; ++j) {
+                    const PartialDev& pd = a.partials[i + min(j, cnt - 1)];
+                    lw[j] = pd.lse[ridx];
+                    x[j] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(pd.out) + ridx * D + sub * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < NBATCH; ++j) widen8<T>(x[j], pv[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NBATCH; ++j) {
+                const float w = j < cnt ? __expf(lw[j] - Ms) : 0.f;
+                den += w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) num[e] = __builtin_fmaf(w, pv[j][e], num[e]);
+            }
+            i += cnt;
+        }
+        const float dinv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) num[j] *= dinv;
+    }
+    const u32x4 pk = {TR::pack2(num[0], num[1]), TR::pack2(num[2], num[3]), TR::pack2(num[4], num[5]),
+                      TR::pack2(num[6], num[7])};
+    *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(a.out) + ridx * D + sub * 8) = pk;
+}
+
+// Packed path for SHORT sequences with one query row per unit (decode with Hq == Hkv, nq == 1 -- C2): a LANE GROUP of
+// D/8 lanes owns one (sequence, kv head) unit, so a wave works on 64 / (D/8) consecutive kv heads of one sequence (4 at
+// D = 128) and walks their keys together: one wave instruction fetches one token's K (or V) rows of those heads = 1 KiB
+// contiguous.  The one-unit-per-wave path spends ~300 instructions per unit outside its key loop (three quarters of a
+// load instruction idle at short lengths, two rounds of cross-lane-group merges, a per-wave epilogue); at C2 that is
+// 32768 waves and 16 us of pure issue time, the whole cost of a step with a short suffix (22 us at S = 1 for 6 us of
+// HBM traffic).  Here a lane group keeps its own (m, l, acc): no cross-group merge at all, a quarter of the waves
+// (measured at C2, fused entry: S = 1 22.2 -> 7.4 us, S = 4 22.4 -> 16.0 us, S = 8 29.9 -> 27.0 us; from S = 16 on the
+// one-unit-per-wave path streams 2-4 % faster -- more loads in flight -- so the choice is made per sequence at RUN time
+// from its length, inside the one kernel the shapes select: capture-safe, no device read on the host).
+constexpr int kPackedMaxLen = 12;
+template <typename T, int D>
+__device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, int ygroup, int len) {
+    using TR = Traits<T>;
+    constexpr int LPK = D / 8;     // lanes per unit
+    constexpr int HPW = 64 / LPK;  // units (kv heads) per wave
+    constexpr int U = 2;           // keys in flight per wave and tensor (x 1 KiB); sequences here are at most kPackedMaxLen long
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane % LPK, hg = lane / LPK;
+    const int h0 = (ygroup * 4 + wave) * HPW;  // first head of this wave
+    if (h0 >= a.Hkv) return;
+    const int hk = h0 + hg;
+    const bool hvalid = hk < a.Hkv;
+    const int hkc = hvalid ? hk : a.Hkv - 1;  // idle lane groups shadow the last head and never store
+
+    const int64_t ridx = (int64_t)b * a.Hq + hkc;  // nq == 1, g == 1: [B, 1, Hq]
+    const u32x4 qp = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.q) + ridx * D + sub * 8);
+    // the first partial (the usual single prefix level), fetched under the K/V stream
+    const bool pre0 = a.n_partials > 0 && !a.partials[0].is_f32;
+    float pl0 = 0.f;
+    u32x4 po0 = {0u, 0u, 0u, 0u};
+    if (pre0) {
+        pl0 = a.partials[0].lse[ridx];
+        po0 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.partials[0].out) + ridx * D + sub * 8);
+    }
+
+    // wave-uniform sequence base (scalar registers) + per-lane 32-bit byte offset (head, dims) -> SADDR-form loads
+    const gchar_p kbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs));
+    const gchar_p vbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs));
+    const unsigned klane = (unsigned)(hkc * a.k_hs * 2 + sub * 16), vlane = (unsigned)(hkc * a.v_hs * 2 + sub * 16);
+    const unsigned krs = (unsigned)(a.k_ts * 2), vrs = (unsigned)(a.v_ts * 2);  // token stride in bytes
+
+    float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const float sc = a.scale_log2e;
+    auto chunk = [&](auto UU_C, int t0) __attribute__((always_inline)) {
+        constexpr int UU = decltype(UU_C)::value;
+        u32x4 kreg[UU], vreg[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            // never predicate the loads: clamp to the last valid key, its score is forced to -inf below
+            const unsigned tc = (unsigned)min(t0 + u, len - 1);
+            kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + (tc * krs + klane)));
+            vreg[u] = __builtin_nontemporal_load((gu32x4_p)(vbu + (tc * vrs + vlane)));
+        }
+        float s[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d = TR::dot2(qp[i], kreg[u][i], d);
+            d = group_sum<LPK>(d);
+            s[u] = (t0 + u < len) ? d * sc : -INFINITY;  // wave-uniform condition
+        }
+        float cmax = s[0];
+#pragma unroll
+        for (int u = 1; u < UU; ++u) cmax = fmaxf(cmax, s[u]);
+        const float mnew = fmaxf(m, cmax);  // finite: t0 < len
+        const float alpha = fast_exp2(m - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            s[u] = fast_exp2(s[u] - mnew);
+            ps += s[u];
+        }
+        l = l * alpha + ps;
+        m = mnew;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            float vf[8];
+            widen8<T>(vreg[u], vf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(s[u], vf[j], acc[j]);
+        }
+    };
+    int t = 0;
+    for (; t + U <= len; t += U) chunk(std::integral_constant<int, U>{}, t);
+    for (; t < len; ++t) chunk(std::integral_constant<int, 1>{}, t);
+
+    if (hvalid) finish_row<T, D, 2>(a, ridx, sub, m, l, acc, pre0, pl0, po0);
+}
+
 template <typename T, int D, int R, int WPU>
 __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
@@ -80,6 +269,14 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
     if (a.sl32) len = a.sl32[b];
     else if (a.sl64) len = (int)a.sl64[b];
     len = max(0, min(len, a.kv_len));
+    if constexpr (R == 1 && WPU == 1 && D == 128) {
+        // short sequence and a packable shape (a.packed, shapes only): the first of every 4 workgroups of this
+        // sequence serves the 16 (D = 128) kv heads of all four with the lane-group layout, the other three leave
+        if (a.packed && len <= kPackedMaxLen) {
+            if ((blockIdx.y & 3) == 0) suffix_packed_body<T, D>(a, b, blockIdx.y >> 2, len);
+            return;
+        }
+    }
 
     // ---- query rows (packed 16-bit pairs, 8 dims per lane) -------------------------------------
     u32x4 qp[R];
@@ -273,90 +470,7 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
         if (row >= a.rows || ks != (r % KPI)) continue;
         const int iq = a.nq == 1 ? 0 : row / a.g, gq = a.nq == 1 ? row : row % a.g;
         const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;  // [B, nq, Hq]
-        const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
-        const float lse_s = l[r] > 0.f ? m[r] * kLn2 + __logf(l[r]) : -INFINITY;
-        if (a.lse && sub == 0) a.lse[ridx] = lse_s;
-        float num[8];
-        if (a.n_partials == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) num[j] = acc[r][j] * inv;
-        } else {
-            const int i0 = pre0 ? 1 : 0;  // partial 0 already sits in registers
-            const float l0 = pl0[r / KPI];
-            // The remaining partials (split-KV slices, further levels) are read four at a time with clamped indices,
-            // so that a batch's loads are all in flight together instead of one memory latency per partial.
-            const int np = a.n_partials;
-            float M = pre0 ? fmaxf(lse_s, l0) : lse_s;
-            for (int i = i0; i < np; i += 4) {
-                float lv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) lv[j] = a.partials[min(i + j, np - 1)].lse[ridx];
-                M = fmaxf(fmaxf(M, fmaxf(lv[0], lv[1])), fmaxf(lv[2], lv[3]));
-            }
-            const float Ms = (M == -INFINITY) ? 0.f : M;
-            const float ws = __expf(lse_s - Ms);
-            float den = ws;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) num[j] = acc[r][j] * (inv * ws);
-            if (pre0) {
-                const float w = __expf(l0 - Ms);
-                den += w;
-                float pv[8];
-                widen8<T>(po0[r / KPI], pv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
-            }
-            for (int i = i0; i < np;) {
-                // a batch = up to 4 consecutive partials of the same element type (slices of one level are adjacent)
-                const bool f32 = a.partials[i].is_f32 != 0;
-                int cnt = 1;
-                while (cnt < 4 && i + cnt < np && (a.partials[i + cnt].is_f32 != 0) == f32) ++cnt;
-                float lw[4];
-                float pv[4][8];
-                if (f32) {
-                    f32x4 x0[4], x1[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const PartialDev& pd = a.partials[i + min(j, cnt - 1)];
-                        const float* po = static_cast<const float*>(pd.out) + ridx * D + sub * 8;
-                        lw[j] = pd.lse[ridx];
-                        x0[j] = *reinterpret_cast<const f32x4*>(po);
-                        x1[j] = *reinterpret_cast<const f32x4*>(po + 4);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            pv[j][e] = x0[j][e];
-                            pv[j][4 + e] = x1[j][e];
-                        }
-                } else {
-                    u32x4 x[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const PartialDev& pd = a.partials[i + min(j, cnt - 1)];
-                        lw[j] = pd.lse[ridx];
-                        x[j] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(pd.out) + ridx * D + sub * 8);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) widen8<T>(x[j], pv[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float w = j < cnt ? __expf(lw[j] - Ms) : 0.f;
-                    den += w;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) num[e] = __builtin_fmaf(w, pv[j][e], num[e]);
-                }
-                i += cnt;
-            }
-            const float dinv = den > 0.f ? 1.0f / den : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) num[j] *= dinv;
-        }
-        u32x4 pk = {TR::pack2(num[0], num[1]), TR::pack2(num[2], num[3]), TR::pack2(num[4], num[5]),
-                    TR::pack2(num[6], num[7])};
-        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(a.out) + ridx * D + sub * 8) = pk;
+        finish_row<T, D>(a, ridx, sub, m[r], l[r], acc[r], pre0, pl0[r / KPI], po0[r / KPI]);
     }
 }
 
@@ -376,8 +490,18 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// packed path: one query row per unit (nq == 1, Hq == Hkv), 32-bit offsets inside a sequence's cache
+static bool suffix_packed_eligible(const SuffixArgs& a, int D) {
+    const int hpw = 64 / (D / 8);
+    const int64_t span = (int64_t)a.kv_len * (a.k_ts > a.v_ts ? a.k_ts : a.v_ts) * 2 +
+                         (int64_t)a.Hkv * (a.k_hs > a.v_hs ? a.k_hs : a.v_hs) * 2;
+    return a.rows == 1 && a.nq == 1 && a.g == 1 && a.Hkv >= hpw && D == 128 && span < ((int64_t)1 << 31);
+}
+
 template <typename T, int D>
-static int launch_suffix_t(const SuffixArgs& a, hipStream_t s) {
+static int launch_suffix_t(const SuffixArgs& a0, hipStream_t s) {
+    SuffixArgs a = a0;
+    a.packed = suffix_packed_eligible(a, D) ? 1 : 0;
     if (a.rows <= 1) return launch_suffix_r<T, D, 1>(a, s);
     if (a.rows <= 2) return launch_suffix_r<T, D, 2>(a, s);
     if (a.rows <= 4) return launch_suffix_r<T, D, 4>(a, s);

@@ -193,3 +193,28 @@ def test_prefix_256_row_workgroups(dt, sk):
     want, wlse = O.flash_attention(q, k, v)
     assert_close(out.float().cpu().numpy(), want, dt, "256-row workgroups: out")
     assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("hq,hkv,nq", [(8, 8, 1), (8, 2, 1), (8, 1, 1), (4, 4, 3)])
+def test_padding_beyond_seq_len_is_never_read_into_the_result(dt, hq, hkv, nq):
+    """The unique cache is handed over whole with seq_lens (llama.py:259-262,569): whatever sits behind a sequence's
+    length -- here NaN and Inf -- must not reach the output (0 * NaN would), for the dot-product and the matrix-core
+    suffix kernels alike, with lengths that end inside a 32-key step."""
+    from hydragen_amd.flash import flash_attention_seqlen
+
+    rng = np.random.default_rng(31 + hq + hkv + nq)
+    B, S, D = 5, 70, 128
+    lens = np.asarray([1, 33, 70, 17, 64], dtype=np.int32)
+    q, k, v = _rand(rng, (B, nq, hq, D), dt), _rand(rng, (B, S, hkv, D), dt), _rand(rng, (B, S, hkv, D), dt)
+    kp, vp = k.copy(), v.copy()
+    for b in range(B):
+        kp[b, lens[b]:] = np.nan
+        vp[b, lens[b]:] = np.inf if b % 2 else np.nan
+    out, lse = flash_attention_seqlen(dev(q, dt), dev(kp, dt), dev(vp, dt), seq_len=dev(lens))
+    torch.cuda.synchronize()
+    want, wlse = O.flash_attention_seqlen(q, k, v, lens)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all(), "padding leaked into the output"
+    assert_close(got, want, dt, "poisoned padding")
+    assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3
