@@ -218,3 +218,30 @@ def test_padding_beyond_seq_len_is_never_read_into_the_result(dt, hq, hkv, nq):
     assert np.isfinite(got).all(), "padding leaked into the output"
     assert_close(got, want, dt, "poisoned padding")
     assert np.abs(lse.cpu().numpy() - wlse).max() < 2e-3
+
+
+def test_cached_parameter_blocks_follow_the_callers_tensors():
+    """The eager host path caches marshalled parameter blocks per (addresses, shapes, strides): repeated calls must keep
+    reading the CURRENT contents of the caller's tensors (seq_lens changed in place, K/V overwritten), and calls with
+    other shapes must not collide."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+
+    dt, rng = "bf16", np.random.default_rng(41)
+    B, Hq, Hkv, D, S, P = 6, 8, 8, 128, 24, 150
+    q = dev(_rand(rng, (B, 1, Hq, D), dt), dt)
+    k, v = dev(_rand(rng, (B, S, Hkv, D), dt), dt), dev(_rand(rng, (B, S, Hkv, D), dt), dt)
+    sk, sv = dev(_rand(rng, (1, P, Hkv, D), dt), dt), dev(_rand(rng, (1, P, Hkv, D), dt), dt)
+    lens = torch.full((B,), 3, dtype=torch.int32, device="cuda:0")
+    f = lambda t: t.float().cpu().numpy()
+    for step in range(4):
+        out = hydragen_attention_nopad(q, k, v, [sk], [sv], seq_len=lens)
+        torch.cuda.synchronize()
+        want = O.hydragen_attention_nopad(f(q), f(k), f(v), [f(sk)], [f(sv)], lens.cpu().numpy())
+        assert_close(f(out), want, dt, f"cached call {step}")
+        lens += 5                       # in place: same tensor, new contents
+        k[:, step].normal_()            # the cache keeps growing between decode steps
+        q.normal_()
+    out2 = hydragen_attention_nopad(q[:4], k[:4], v[:4], [sk], [sv], seq_len=lens[:4])
+    torch.cuda.synchronize()
+    want2 = O.hydragen_attention_nopad(f(q[:4]), f(k[:4]), f(v[:4]), [f(sk)], [f(sv)], lens[:4].cpu().numpy())
+    assert_close(f(out2), want2, dt, "other shapes")
