@@ -474,6 +474,15 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
     constexpr int RING_BYTES = (KG == 2 ? 512 : 256) * RB;
     float* mlbuf = reinterpret_cast<float*>(smem + RING_BYTES);  // [4 waves][QB][2][64] (KG = 2 merge)
 
+    unsigned tst[6] = {0, 0, 0, 0, 0, 0};  // ABL bit 11: cycle stamps of workgroup 0 (development builds only)
+    auto stampk = [&](int k) __attribute__((always_inline)) {
+        if constexpr ((ABL & 2048) != 0) {
+            uint64_t t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            tst[k] = (unsigned)t;
+        }
+    };
+    stampk(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -851,56 +860,69 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
 #define HYD_IC(x) integral_constant<int, (x)>{}
     const int kwave = kbeg + kg * 64;  // first key of this wave's half of tile 0
     auto kw_of = [&](int b) { return KG == 2 ? kwave + (b >> 1) * 128 + (b & 1) * 32 : kwave + b * 32; };
-    // Every iteration i = -1 .. NB runs the same code: stages whose block does not exist work on zeros /
-    // fully masked scores (QK(NB) and SM(-1), SM(NB) are harmless, PV(-2), PV(-1) add P = 0 times finite V).
+    // Iterations i = -1 .. NB; the pipeline's fill (i = -1: QK(0) only; i = 0: QK(1) + softmax(0)) and drain
+    // (i = NB-1: softmax + PV, no QK; i = NB: PV(NB-1) only) run their own, shorter instantiations of the iteration.
     // Cold start: only what the first iteration needs is waited for (Q, K blocks 0 and 1); K block 2 and V block 0 are
-    // issued behind that wait and land during iterations -1 / 0; V slots 2 and 3 are zero-filled in LDS.
+    // issued behind that wait and land during iterations -1 / 0.
     if (NB > 0) {
         dma_block(0, false);
         dma_block(1, false);
-        // slots 2 and 3 of the V ring (= tile buffer 1) are read by PV(-2) / PV(-1) with P = 0: must hold finite data
-        for (int off = tid * 16; off < V_BYTES; off += 256 * 16)  // V_BYTES = two slots in either layout
-            *reinterpret_cast<u32x4*>(smem + V_OFF + V_BYTES + off) = u32x4{0u, 0u, 0u, 0u};
     }
     // Wait for the Q fragments (asm loads: hipcc does not count them) and the first two K blocks; every consumer is
     // a volatile asm statement behind this one.
+    stampk(1);
     dma_wait_w<0>();
     if (NB > 0) {
         dma_block(2, false);  // covered by the counted wait that ends iteration -1
         dma_block(0, true);
     }
     __syncthreads();
+    stampk(2);
     if (NB > 0) {
 #pragma unroll
         for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, slot_k(0));
-#pragma unroll
-        for (int p = 0; p < PDV; ++p) { vfr[p][0] = ldv_at(p, 0, slot_v(2)); vfr[p][1] = ldv_at(p, 1, slot_v(2)); }
         // ii = i0 + R = -1 + R (mod 4), so every ring slot is a compile-time constant:
         //   reads  K block ii+1 -> slot R, V block ii-1 -> slot (R+2)&3;  next iteration: (R+1)&3, (R+3)&3
         //   writes K block ii+4 -> slot (R+3)&3, V block ii+2 -> slot (R+1)&3.      ii odd <=> R even.
-#define HYD_IT(R, SW, SR, PW, PR)                                                                            \
+        // FL: 1 QK | 2 softmax | 4 PV | 8 masking possible | 16 / 32: the next iteration has QK / PV (fragment prefetch)
+        constexpr int FL_FULL = 7 + 8 + 16 + 32, FL_FIRST = 1 + 16, FL_SECOND = 1 + 2 + 8 + 16 + 32,
+                      FL_PENULT = 2 + 4 + 8 + 32, FL_LAST = 4;
+#define HYD_IT(R, FLV, SW, SR, PW, PR)                                                                       \
     {                                                                                                        \
         const int ii = i0 + (R);                                                                             \
         iter(HYD_IC(slot_k((R) & 3)), HYD_IC(slot_v(((R) + 2) & 3)), HYD_IC(slot_k(((R) + 1) & 3)),          \
-             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(7 + 8 + 16 + 32), HYD_IC(1), SW, SR, PW, PR, kw_of(ii),   \
+             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(FLV), HYD_IC(1), SW, SR, PW, PR, kw_of(ii),               \
              ii >= 0 && ii < NB, soff_of(ii + 4, k_ts2), soff_of(ii + 2, v_ts2),                             \
              slot_k(((R) + 3) & 3), slot_v(((R) + 1) & 3));                                                  \
         dma_wait_w<2 * NLB>();                                                                               \
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();                                                       \
     }
-        for (int i0 = -1;; i0 += 4) {
-            HYD_IT(0, S0, S1, P1, P0)
-            HYD_IT(1, S1, S0, P0, P1)
-            if (i0 + 2 >= NB) break;
-            HYD_IT(2, S0, S1, P1, P0)
-            HYD_IT(3, S1, S0, P0, P1)
-            if (i0 + 4 >= NB) break;
+        int i0 = -1;
+        HYD_IT(0, FL_FIRST, S0, S1, P1, P0)
+        HYD_IT(1, FL_SECOND, S1, S0, P0, P1)
+        for (;;) {
+            if (i0 + 4 >= NB) {
+                HYD_IT(2, FL_PENULT, S0, S1, P1, P0)
+                HYD_IT(3, FL_LAST, S1, S0, P0, P1)
+                break;
+            }
+            HYD_IT(2, FL_FULL, S0, S1, P1, P0)
+            HYD_IT(3, FL_FULL, S1, S0, P0, P1)
+            i0 += 4;
+            if (i0 + 2 >= NB) {
+                HYD_IT(0, FL_PENULT, S0, S1, P1, P0)
+                HYD_IT(1, FL_LAST, S1, S0, P0, P1)
+                break;
+            }
+            HYD_IT(0, FL_FULL, S0, S1, P1, P0)
+            HYD_IT(1, FL_FULL, S1, S0, P0, P1)
         }
 #undef HYD_IT
         dma_wait_w<0>();
         __syncthreads();  // nothing in flight, everyone done with the rings before the merge reuses them
     }
     acc_drain();
+    stampk(3);
 #undef HYD_IC
 
     // ---- merge the two key halves through LDS (KG = 2), normalise, store ------------------------------------
@@ -932,6 +954,7 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
         }
         __syncthreads();
     }
+    stampk(4);
     const int pw = wave ^ 2;  // partner wave (KG = 2)
     static_for<QB>([&](auto B_) __attribute__((always_inline)) {
         constexpr int qb = decltype(B_)::value;
@@ -997,6 +1020,15 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
             a.lse[(int64_t)sp * a.lse_split_stride + idx] = lse;
         }
     });
+    if constexpr ((ABL & 2048) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stampk(5);
+        if (blockIdx.x == 0 && lane < 6) {
+            unsigned tv = tst[0];
+            for (int q_ = 1; q_ < 6; ++q_) tv = lane == q_ ? tst[q_] : tv;
+            reinterpret_cast<unsigned*>(a.lse)[(size_t)a.B * a.nq * a.Hq + wave * 8 + lane] = tv;
+        }
+    }
 }
 
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
@@ -1016,7 +1048,7 @@ int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int gr
     if (a.dbg && dtype == HYD_BF16 && D == 128 && !causal && a.wg_rows == 128) {
         switch (a.dbg) {
 #define HYD_ABL(N) case N: return launch_prefix_w64_t<BF16, 128, false, 2, N>(a, grid, s);
-            HYD_ABL(1) HYD_ABL(4) HYD_ABL(5) HYD_ABL(8) HYD_ABL(32) HYD_ABL(64) HYD_ABL(65) HYD_ABL(128)
+            HYD_ABL(1) HYD_ABL(4) HYD_ABL(5) HYD_ABL(8) HYD_ABL(32) HYD_ABL(64) HYD_ABL(65) HYD_ABL(128) HYD_ABL(2048)
 #undef HYD_ABL
             default: break;
         }

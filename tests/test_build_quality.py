@@ -21,9 +21,19 @@ LIMITS = {
 }
 
 
+_ASM_CACHE = {}
+
+
+def _device_asm(src: str) -> str:
+    """gfx950 assembly of one source file (compiled once per test session: the prefix kernel takes ~90 s)."""
+    if src not in _ASM_CACHE:
+        _ASM_CACHE[src] = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                          str(CSRC / src), "-o", "-"], capture_output=True, text=True, check=True).stdout
+    return _ASM_CACHE[src]
+
+
 def _metadata(src: str):
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                          str(CSRC / src), "-o", "-"], capture_output=True, text=True, check=True).stdout
+    out = _device_asm(src)
     kernels = []
     for blk in out.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
@@ -53,8 +63,7 @@ def test_prefix_kernel_owns_its_accumulator_registers():
     """prefix_attn_w64.hip keeps the O accumulators and the Q fragments in literal AGPRs (a[0:191]) that only its own
     inline-asm statements name.  That is safe only while hipcc itself never touches an AGPR in those kernels (it would,
     for spills): no instruction outside ;;#ASMSTART / ;;#ASMEND may name one, and every kernel must allocate >= 160."""
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                          str(CSRC / "prefix_attn_w64.hip"), "-o", "-"], capture_output=True, text=True, check=True).stdout
+    out = _device_asm("prefix_attn_w64.hip")
     inasm, bad = False, []
     for line in out.splitlines():
         t = line.strip()

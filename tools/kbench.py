@@ -55,10 +55,10 @@ if a.what == "prefix":
         fl = 4.0 * a.B * a.Hq * P * a.D
         print(f"prefix P={P:6d}  {us:9.2f} us  {fl/us/1e6:8.1f} TFLOP/s  ({fl/us/1e6/2500*100:5.1f}% of 2.5PF)")
         import os
-        if int(os.environ.get("HYD_DBG", "0")) & 64:  # ablation build: cycle stamps of one iteration, 8 waves of block 0
+        if int(os.environ.get("HYD_DBG", "0")) & 2048:  # ablation build: cycle stamps of the 4 waves of workgroup 0
             torch.cuda.synchronize()
             ts = lse.view(torch.int32).flatten()[a.B * a.Hq:a.B * a.Hq + 64].cpu().view(8, 8)
-            for w in range(8):
+            for w in range(4):
                 d = [(int(ts[w, k]) - int(ts[w, 0])) & 0xffffffff for k in range(6)]
                 print(f"   wave {w}: setup+issue {d[1]}  first wait+barrier {d[2]-d[1]}  loop {d[3]-d[2]}  merge write+barrier {d[4]-d[3]}  combine+stores {d[5]-d[4]}  | kernel {d[5]} ticks")
 else:
