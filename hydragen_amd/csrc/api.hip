@@ -103,6 +103,20 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMa
     int split_len = (int)align_up((size_t)((p->kv_len + ns - 1) / ns), 128);
     if (split_len == 0) split_len = 128;
     ns = p->kv_len > 0 ? (p->kv_len + split_len - 1) / split_len : 1;
+    // The prefix kernel addresses one split's keys through a 32-bit buffer resource + scalar offset (it issues blocks up
+    // to 4 x 32 rows past the end, which must not wrap): cut longer spans into more splits, or refuse.
+    {
+        const int64_t ts = p->k_tok_stride > p->v_tok_stride ? p->k_tok_stride : p->v_tok_stride;
+        const int64_t max_rows = ts > 0 ? (((int64_t)1 << 31) / (ts * 2)) - 512 : (int64_t)1 << 30;
+        if (max_rows < 128) return fail(HYD_ERR_UNSUPPORTED, "token stride %lld elements is too large for 32-bit key offsets", (long long)ts);
+        if (split_len > max_rows) {
+            split_len = (int)(max_rows / 128 * 128);
+            ns = (p->kv_len + split_len - 1) / split_len;
+            if (ns > kMaxSplits || p->cu_seqlens_q)
+                return fail(HYD_ERR_UNSUPPORTED, "%d keys at a token stride of %lld elements exceed the 2 GiB per split the prefix pass addresses",
+                            p->kv_len, (long long)ts);
+        }
+    }
     pl->nsplit = ns;
     pl->split_len = split_len;
     const int64_t grid = units * ns;

@@ -859,7 +859,6 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
     using std::integral_constant;
 #define HYD_IC(x) integral_constant<int, (x)>{}
     const int kwave = kbeg + kg * 64;  // first key of this wave's half of tile 0
-    auto kw_of = [&](int b) { return KG == 2 ? kwave + (b >> 1) * 128 + (b & 1) * 32 : kwave + b * 32; };
     // Iterations i = -1 .. NB; the pipeline's fill (i = -1: QK(0) only; i = 0: QK(1) + softmax(0)) and drain
     // (i = NB-1: softmax + PV, no QK; i = NB: PV(NB-1) only) run their own, shorter instantiations of the iteration.
     // Cold start: only what the first iteration needs is waited for (Q, K blocks 0 and 1); K block 2 and V block 0 are
@@ -887,13 +886,23 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
         // FL: 1 QK | 2 softmax | 4 PV | 8 masking possible | 16 / 32: the next iteration has QK / PV (fragment prefetch)
         constexpr int FL_FULL = 7 + 8 + 16 + 32, FL_FIRST = 1 + 16, FL_SECOND = 1 + 2 + 8 + 16 + 32,
                       FL_PENULT = 2 + 4 + 8 + 32, FL_LAST = 4;
+        // Scalars that advance by one 32-key block per iteration (kept incremental: the loop is issue-bound and every
+        // scalar instruction between two MFMAs costs a slot): byte offset of K block ii+4 and of V block ii+2 inside
+        // their buffer resources (blocks past the keys only ever exceed num_records: zero fill), first key of block ii.
+        // Block b -> b+1 advances 32 rows, or 96 when b is odd and the key halves interleave (KG = 2).
+        const unsigned k_lo = 32u * k_ts2, v_lo = 32u * v_ts2;
+        const unsigned k_hi = KG == 2 ? 96u * k_ts2 : k_lo, v_hi = KG == 2 ? 96u * v_ts2 : v_lo;
+        unsigned kso = (unsigned)row0_of(3) * k_ts2, vso = (unsigned)row0_of(1) * v_ts2;
+        int kwv = kwave + (KG == 2 ? -96 : -32);
 #define HYD_IT(R, FLV, SW, SR, PW, PR)                                                                       \
     {                                                                                                        \
-        const int ii = i0 + (R);                                                                             \
         iter(HYD_IC(slot_k((R) & 3)), HYD_IC(slot_v(((R) + 2) & 3)), HYD_IC(slot_k(((R) + 1) & 3)),          \
-             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(FLV), HYD_IC(1), SW, SR, PW, PR, kw_of(ii),               \
-             ii >= 0 && ii < NB, soff_of(ii + 4, k_ts2), soff_of(ii + 2, v_ts2),                             \
+             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(FLV), HYD_IC(1), SW, SR, PW, PR, kwv, true, kso, vso,     \
              slot_k(((R) + 3) & 3), slot_v(((R) + 1) & 3));                                                  \
+        /* ii = i0 + R is odd <=> R even: blocks ii, ii+2, ii+4 share its parity */                          \
+        kso += ((R) & 1) ? k_lo : k_hi;                                                                      \
+        vso += ((R) & 1) ? v_lo : v_hi;                                                                      \
+        kwv += ((R) & 1) ? 32 : (KG == 2 ? 96 : 32);                                                         \
         dma_wait_w<2 * NLB>();                                                                               \
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();                                                       \
     }
