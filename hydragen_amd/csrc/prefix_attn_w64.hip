@@ -897,7 +897,8 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
 #define HYD_IT(R, FLV, SW, SR, PW, PR)                                                                       \
     {                                                                                                        \
         iter(HYD_IC(slot_k((R) & 3)), HYD_IC(slot_v(((R) + 2) & 3)), HYD_IC(slot_k(((R) + 1) & 3)),          \
-             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(FLV), HYD_IC(1), SW, SR, PW, PR, kwv, true, kso, vso,     \
+             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(FLV), HYD_IC(1), SW, SR, PW, PR, kwv, true,               \
+             __builtin_amdgcn_readfirstlane(kso), __builtin_amdgcn_readfirstlane(vso),                        \
              slot_k(((R) + 3) & 3), slot_v(((R) + 1) & 3));                                                  \
         /* ii = i0 + R is odd <=> R even: blocks ii, ii+2, ii+4 share its parity */                          \
         kso += ((R) & 1) ? k_lo : k_hi;                                                                      \

@@ -89,17 +89,24 @@ __device__ __forceinline__ float quad_sum(float x) {
 
 }  // namespace
 
-template <typename T, int D>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+// WPU: waves per unit.  1: a one-wave workgroup per unit (producer and consumer of the LDS tile are the same wave, no
+// barriers).  4: the unit's 32-key steps are dealt round-robin to the 4 waves of a 256-thread workgroup and their
+// (m, l, O) merged through LDS at the end -- for shapes with too few units to fill the chip with one wave each (C3: 1024
+// units on 256 CUs, C5: 2048), where nothing but more waves hides the per-step load latency.
+template <typename T, int D, int WPU>
+__global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(4, 4))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int RB = D * 2;        // bytes per K/V row
     constexpr int NCH = D / 32;      // 32-dim chunks of the QK^T contraction
     constexpr int NDB = D / 16;      // 16-wide d blocks of O^T
     constexpr int RPI = 1024 / RB;   // V rows per DMA instruction
     constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key V tile
-    __shared__ __attribute__((aligned(1024))) char vtile[32 * RB];
+    __shared__ __attribute__((aligned(1024))) char vtiles[WPU][32 * RB];  // 32 * RB = 16 rows * D floats: reused by the merge
+    __shared__ float mlx[WPU][2][16];
+    const int wave = WPU == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    char* vtile = vtiles[wave];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int b = blockIdx.x, hk = blockIdx.y, row0 = blockIdx.z * 16;
 
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const float sc = a.scale_log2e;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    for (int key0 = 0; key0 < len; key0 += 32) {
+    for (int key0 = wave * 32; key0 < len; key0 += 32 * WPU) {
         // all loads of the step first (K to registers, V to LDS), one wait; other waves of the CU hide the latency
         const unsigned ksoff = (unsigned)key0 * k_ts2, vsoff = (unsigned)key0 * v_ts2;
         u32x4 kf[2][NCH];
@@ -212,6 +219,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         // the next step's DMA overwrites the tile: every transposing read above has returned (the MFMAs consumed them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- merge the WPU waves of the unit: every wave leaves (m, l, O^T) in its own tile, wave 0 folds them -------
+    if constexpr (WPU > 1) {
+        float* mine = reinterpret_cast<float*>(vtile);  // [16 rows][D]: O (unnormalised)
+        // lane (row l15, key group g4) holds O^T[d = 16 db + 4 g4 + i][row l15] in o[db][i]; m / l are equal over g4
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+            *reinterpret_cast<f32x4*>(mine + l15 * D + 16 * db + 4 * g4) = o[db];
+        if (g4 == 0) {
+            mlx[wave][0][l15] = m_run;
+            mlx[wave][1][l15] = l_run;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < WPU; ++w) {
+            const float* oth = reinterpret_cast<const float*>(vtiles[w]);
+            const float m2 = mlx[w][0][l15], l2 = mlx[w][1][l15];
+            const float mf = fmaxf(m_run, m2);
+            const float ms = (mf == -INFINITY) ? 0.f : mf;
+            const float a1 = fast_exp2(m_run - ms), a2 = fast_exp2(m2 - ms);
+            l_run = l_run * a1 + l2 * a2;
+            m_run = mf;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) o[db] = o[db] * a1 + *reinterpret_cast<const f32x4*>(oth + l15 * D + 16 * db + 4 * g4) * a2;
+        }
     }
 
     // ---- epilogue: normalise, merge with the prefix partials (attention.py:21-43), store ---------------------
@@ -283,8 +317,13 @@ bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
 
 template <typename T, int D>
 static int launch_gqa_t(const SuffixArgs& a, hipStream_t s) {
-    dim3 grid(a.B, a.Hkv, (a.rows + 15) / 16);
-    hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D>), grid, dim3(64), 0, s, a);
+    const int chunks = (a.rows + 15) / 16;
+    // shapes only: fewer than 4 one-wave units per CU (measured: B=32, 8/1 heads, 1152 keys 48 -> 31 us; at 1024 and
+    // 2048 units -- C3, C5 -- one wave per unit is as fast or faster), and enough keys to deal out
+    const bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len >= 128;
+    dim3 grid(a.B, a.Hkv, chunks);
+    if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1>), grid, dim3(64), 0, s, a);
     return (int)hipGetLastError();
 }
 
