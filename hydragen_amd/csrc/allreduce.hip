@@ -30,7 +30,7 @@ constexpr int kArFlagWords = 2 * kArMaxWorld * kArFlagStride;  // two phases x w
 constexpr int kArLocalWords = 64;           // epoch, arrival counter, status (never read by peers)
 constexpr size_t kArHeaderBytes = (kArFlagWords + kArLocalWords) * sizeof(uint32_t);  // 2304 B -> padded to 4 KiB
 constexpr size_t kArHeaderPad = 4096;
-constexpr unsigned long long kArSpinLimit = 2000000000ull;  // ~1 s of s_memtime ticks at 2.1 GHz
+constexpr uint32_t kArSpinLimit = 1u << 24;  // polls; one poll (s_sleep 8 + a flag load) measured at ~0.3 us: ~5 s
 
 struct ArArgs {
     char* block[kArMaxWorld];  // every rank's shared block as mapped in this process; block[rank] is our own
@@ -49,14 +49,15 @@ __device__ __forceinline__ uint32_t* local_ptr(char* block, int i) {
     return reinterpret_cast<uint32_t*>(block) + kArFlagWords + i;
 }
 
-// one lane waits until *flag >= epoch; returns false on timeout
+// one lane waits until *flag >= epoch; returns false after kArSpinLimit polls.  The bound counts polls, not clock
+// ticks: a wave that the scheduler saves and restores (several processes sharing one device) can resume on another
+// XCD, whose s_memtime has a different base -- a clock difference across that switch reads as an instant timeout.
 __device__ __forceinline__ bool wait_flag(uint32_t* flag, uint32_t epoch) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    for (uint32_t n = 0; n < kArSpinLimit; ++n) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) return true;
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_readcyclecounter() - t0 > kArSpinLimit) return false;
     }
-    return true;
+    return false;
 }
 
 template <typename T>
@@ -69,10 +70,13 @@ __device__ __forceinline__ void add8(float (&acc)[8], const u32x4& v) {
     }
 }
 
-// Stage the input where the peers can read it and announce it (phase-0 flags).  Separate launch: the announcement
-// must follow the complete copy, and a kernel boundary is the cheapest grid-wide ordering point.
+// Stage the input where the peers can read it, and announce it (phase-0 flags) from the LAST workgroup to finish:
+// every workgroup writes back its own XCD's L2 (system-scope release) before it takes its ticket, so when the last
+// ticket is drawn the whole staged tensor is in memory -- the announcement does not lean on what the boundary between
+// two kernels of one queue flushes.
 __global__ __launch_bounds__(256) void ar_stage_kernel(const ArArgs a, int elt_bytes) {
     char* mine = a.block[a.rank];
+    __shared__ uint32_t s_last;
     const size_t bytes = (size_t)a.count * elt_bytes;
     const u32x4* src = static_cast<const u32x4*>(a.in);
     u32x4* dst = reinterpret_cast<u32x4*>(mine + kArHeaderPad);
@@ -80,6 +84,21 @@ __global__ __launch_bounds__(256) void ar_stage_kernel(const ArArgs a, int elt_b
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) {  // tail bytes (count is not a multiple of 16 bytes)
         mine[kArHeaderPad + n16 * 16 + threadIdx.x] = static_cast<const char*>(a.in)[n16 * 16 + threadIdx.x];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(local_ptr(mine, 3), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) {
+        const uint32_t epoch = __hip_atomic_load(local_ptr(mine, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if ((int)threadIdx.x < a.world) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(flag_ptr(a.block[threadIdx.x], 0, a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(local_ptr(mine, 3), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -93,16 +112,15 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
     __shared__ uint32_t s_epoch, s_ok, s_last;
     const int tid = threadIdx.x;
     if (tid == 0) {
-        s_epoch = *epoch_w + 1;  // every rank runs the same sequence of calls: epochs agree without communication
+        // every rank runs the same sequence of calls: epochs agree without communication.  The block's local words are
+        // only ever touched by agent-scope atomics (a plain store next to atomic adds on the same word is not
+        // coherent across the XCDs' L2s).
+        s_epoch = __hip_atomic_load(epoch_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         s_ok = 1;
     }
     __syncthreads();
     const uint32_t epoch = s_epoch;
-    // ---- announce our staged input (the stage kernel before us on this stream has completed) and wait for the peers'
-    if (blockIdx.x == 0 && tid < a.world) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the staged bytes are visible before the flag
-        __hip_atomic_store(flag_ptr(a.block[tid], 0, a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    // ---- wait for every rank's staged input (announced by the stage kernels) ---------------------------------
     if (tid < a.world) {
         if (!wait_flag(flag_ptr(mine, 0, tid), epoch)) s_ok = 0;
     }
@@ -170,10 +188,11 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
         __hip_atomic_store(flag_ptr(a.block[tid], 1, a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (s_last && tid == 0) {
-        *arrive_w = 0;      // ready for the next call (stream order: nobody of this launch reads it again)
-        *epoch_w = epoch;
-        if (!ok1) *status_w = 1u;
+        // ready for the next call (every workgroup of this launch has arrived and read the epoch)
+        __hip_atomic_store(arrive_w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(epoch_w, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!ok1 && tid == 0) __hip_atomic_store(status_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- shot 2: gather every peer's reduced slice ----------------------------------------------------------
     for (int q = 1; q < a.world; ++q) {
         const int p = (a.rank + q) % a.world;  // start with a different peer on every rank: all links busy
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         const bool ok2 = s_ok != 0;
-        if (!ok2 && tid == 0 && blockIdx.x == 0) *status_w = 2u;
+        if (!ok2 && tid == 0) __hip_atomic_store(status_w, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t p0 = (int64_t)p * a.slice, p1 = a.count < p0 + a.slice ? a.count : p0 + a.slice;
         const int64_t nv = p1 > p0 ? (p1 - p0 + 7) / 8 : 0;
         const char* src = a.block[p] + kArHeaderPad + a.stage_bytes;

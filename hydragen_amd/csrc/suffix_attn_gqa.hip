@@ -94,7 +94,7 @@ __device__ __forceinline__ float quad_sum(float x) {
 // (m, l, O) merged through LDS at the end -- for shapes with too few units to fill the chip with one wave each (C3: 1024
 // units on 256 CUs, C5: 2048), where nothing but more waves hides the per-step load latency.
 template <typename T, int D, int WPU>
-__global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(4, 4))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+__global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(WPU == 4 ? 2 : 4, WPU == 4 ? 2 : 4))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int RB = D * 2;        // bytes per K/V row
     constexpr int NCH = D / 32;      // 32-dim chunks of the QK^T contraction

@@ -8,8 +8,8 @@ exchange the IPC handles of the per-rank shared blocks.
     comm.all_reduce_(x)                           # in place, on torch's current stream; HIP-graph capturable
     hydragen_amd.tp.use_xgmi_allreduce(comm)      # route tp.all_reduce_sum through it
 
-The shared block is a raw hipMalloc allocation (hipIpcGetMemHandle needs an allocation base, which a tensor of the
-caching allocator is not); it is released in `close()`.
+The shared block is a raw, uncached HIP allocation (hipIpcGetMemHandle needs an allocation base, which a tensor of
+the caching allocator is not); it is released in `close()`.
 """
 
 from __future__ import annotations
@@ -28,14 +28,30 @@ _hip = None
 
 
 def _runtime():
+    """The HIP runtime torch already mapped (by its path in /proc/self/maps: a second copy of libamdhip64 found through
+    the loader's search path would be a second runtime instance in this process)."""
     global _hip
     if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")  # the runtime torch already mapped
+        import torch  # noqa: F401
+        path = "libamdhip64.so"
+        try:
+            for line in open("/proc/self/maps"):
+                if "libamdhip64.so" in line:
+                    path = line.split()[-1]
+                    break
+        except OSError:
+            pass
+        _hip = C.CDLL(path)
         _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
         _hip.hipFree.argtypes = [C.c_void_p]
         _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     return _hip
+
+
+_HIP_DEVICE_MALLOC_UNCACHED = 0x3
+_HIP_DEVICE_MALLOC_FINEGRAINED = 0x1
 
 
 class XgmiAllReduce:
@@ -53,8 +69,12 @@ class XgmiAllReduce:
         hip = _runtime()
         with torch.cuda.device(self.device):
             own = C.c_void_p()
-            if hip.hipMalloc(C.byref(own), self.block_bytes) != 0:
-                raise RuntimeError("hipMalloc of the all-reduce block failed")
+            # Uncached (else fine-grained) device memory: peers write the block's flags and read its staged data over
+            # the fabric, which does not probe the owner's L2 for ordinary coarse-grained allocations.
+            self.uncached = hip.hipExtMallocWithFlags(C.byref(own), self.block_bytes, _HIP_DEVICE_MALLOC_UNCACHED) == 0
+            if not self.uncached:
+                if hip.hipExtMallocWithFlags(C.byref(own), self.block_bytes, _HIP_DEVICE_MALLOC_FINEGRAINED) != 0:
+                    raise RuntimeError("no uncached / fine-grained device allocation for the all-reduce block")
             hip.hipMemset(own, 0, self.block_bytes)
             torch.cuda.synchronize()
             handle = (C.c_ubyte * 64)()

@@ -66,9 +66,10 @@ def _worker(rank, world, port, ret):
             assert err <= 2.0 ** -7, (rank, "graph", rep, err)
         assert comm.status() == 0
         dist.barrier()
+        unc = comm.uncached
         comm.close()
         dist.destroy_process_group()
-        ret.put((rank, "ok", worst))
+        ret.put((rank, "ok", (worst, unc)))
     except Exception as e:  # report instead of hanging the parent
         import traceback
         ret.put((rank, "fail", traceback.format_exc()))
@@ -88,3 +89,38 @@ def test_xgmi_allreduce_two_ranks_on_one_gpu():
         p.join(60)
     for rank, state, info in res:
         assert state == "ok", f"rank {rank}: {info}"
+    print("worst error, uncached block:", [info for _, _, info in res])
+
+
+def test_missing_peer_times_out_with_status():
+    """A peer that never shows up: the call must finish (bounded polls), leave the input untouched and report it in
+    the status word -- not hang the stream.  The 'peer' is a second, silent block in this process."""
+    import ctypes as C
+    import time
+
+    from hydragen_amd import _lib
+    from hydragen_amd._lib import HYD_BF16, AllReduceParams
+
+    lib = _lib.load()
+    max_bytes = 1 << 20
+    nbytes = lib.hyd_allreduce_block_bytes(2, max_bytes)
+    blocks_t = [torch.zeros(nbytes, device="cuda", dtype=torch.uint8) for _ in range(2)]
+    blocks = (C.c_void_p * 2)(*[b.data_ptr() for b in blocks_t])
+    x = torch.randn(4096, device="cuda", dtype=torch.bfloat16)
+    x0 = x.clone()
+    p = AllReduceParams()
+    p.blocks = C.cast(blocks, C.POINTER(C.c_void_p))
+    p.in_, p.out, p.count = x.data_ptr(), x.data_ptr(), x.numel()
+    p.max_bytes, p.dtype, p.rank, p.world = max_bytes, HYD_BF16, 0, 2
+    t0 = time.time()
+    _lib.check(lib.hyd_allreduce_sum(C.byref(p), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    word = torch.empty(1, dtype=torch.int32)
+    status_ptr = lib.hyd_allreduce_status(C.c_void_p(blocks_t[0].data_ptr()))
+    off = (status_ptr if isinstance(status_ptr, int) else C.cast(status_ptr, C.c_void_p).value) - blocks_t[0].data_ptr()
+    status = int(blocks_t[0][off:off + 4].view(torch.int32).item())
+    print(f"missing peer: returned after {dt:.2f} s with status {status}")
+    assert status != 0
+    assert dt < 60
+    assert torch.equal(x, x0)

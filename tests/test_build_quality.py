@@ -14,7 +14,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # file -> (max VGPRs per kernel matching the regex)
 LIMITS = {
     "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512)],   # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs)
-    "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 128)],  # 4 waves / SIMD
+    # 1 wave per unit: 4 waves / SIMD; the 4-waves-per-unit variant only runs when the grid cannot fill the chip anyway
+    "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256), (r"suffix_attn_gqa_kernelINS_\w+ELi\d+ELi1EE", 128)],
     "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1E", 80)],  # MHA decode: 6 waves / SIMD
     "combine.hip": [(r"combine", 128)],
     "rope_append.hip": [(r"rope_append", 128)],
