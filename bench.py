@@ -391,13 +391,15 @@ def _stats(us):
     return {"mean_us": mean, "std_us": std, "rstd": std / mean if mean else 0.0, "n": len(us)}
 
 
-def _timed_replays(graph, iters, flush):
+def _timed_replays(graph, iters, flush, clean=None):
     for _ in range(3):
         graph.replay()
     out = []
     for _ in range(iters):
         if flush is not None:
             flush.add_(1)  # 512 MB read-modify-write: evicts L2 and the 256 MB Infinity Cache (microbenchmark.py:24-47)
+        if clean is not None:
+            clean.sum()    # 512 MB read only: pushes the flush's DIRTY lines out before the timed replay
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         graph.replay()
@@ -457,21 +459,28 @@ def reference_protocol(ops, q, sk, sv, k, v, sweep, iters, with_nosharing):
     B, _, Hq, D = q.shape
     P = sk.shape[1]
     flush = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=dev)
+    clean = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=dev)
     rows = {}
     for s in sweep:
         g = _capture(lambda: ops.fused(s, torch.cuda.current_stream().cuda_stream))
         rows[s] = {"hydragen_flushed": _stats(_timed_replays(g, iters, flush)),
+                   "hydragen_flushed_clean": _stats(_timed_replays(g, iters, flush, clean)),
                    "hydragen_back_to_back": _stats(_timed_replays(g, iters, None))}
         del g
+    del clean
     out = {
         "protocol": "HIP-graph replay of one hyd_decode_attn_fused call, HIP events per replay, 512 MB flush between "
-                    "replays (and the same replays back to back); hydragen/benchmark_utils.py:82-170, scripts/microbenchmark.py:24-47",
+                    "replays (and the same replays back to back); hydragen/benchmark_utils.py:82-170, scripts/microbenchmark.py:24-47. "
+                    "The flush is a WRITE, as the reference's: on MI355X the 256 MB Infinity Cache then holds dirty lines "
+                    "whose write-back is charged to the timed call (C5: +45 us); hydragen_flushed_clean reads a second "
+                    "512 MB buffer after the flush, so the timed call starts cold but with nothing to write back",
         "iters": iters, "by_suffix_len": rows,
     }
     flagged = [s for s, r in rows.items() if r["hydragen_flushed"]["rstd"] > 0.10]  # scripts/synth.py:240-245
     if flagged:
         out["rstd_over_10pct_at"] = flagged
     out["hydragen_flushed_mean_us"] = sum(r["hydragen_flushed"]["mean_us"] for r in rows.values()) / len(rows)
+    out["hydragen_flushed_clean_mean_us"] = sum(r["hydragen_flushed_clean"]["mean_us"] for r in rows.values()) / len(rows)
     out["hydragen_back_to_back_mean_us"] = sum(r["hydragen_back_to_back"]["mean_us"] for r in rows.values()) / len(rows)
     if not with_nosharing:
         return out

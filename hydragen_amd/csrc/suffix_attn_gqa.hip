@@ -18,26 +18,30 @@
 //   O^T += V^T . P^T   D/16 x MFMA, P^T converted in registers (the contraction index is permuted to the
 //        accumulator layout, keys {4j..4j+3, 16+4j..}, so no data moves)
 // One wave per workgroup: producer and consumer of the LDS tile are the same wave, no barriers.
+//
+// Software pipeline: the loads of step i+1 (K fragments and the V tile) are issued before step i is computed and the
+// wait in front of step i is a counted one (s_waitcnt vmcnt(<loads of step i+1>)), so a wave always has one to two
+// 16 KiB steps in flight.  That takes two K register sets and two LDS tiles.  The K sets live in literal AGPRs
+// a[0:63], named only by this file's asm statements (the loads that fill them and the QK MFMAs that read them as the A
+// operand): a compiler-allocated destination of an asm-issued load could legally be copied or spilled by hipcc while
+// the load is still in flight.  (Same technique as prefix_attn_w64.hip; tests/test_build_quality.py audits it.)
+#include <cstdlib>
+#include <type_traits>
+
 #include "hyd_kernels.h"
 
 namespace hyd {
 
 namespace {
 
+// acc += a . b on the matrix cores, operands and accumulator in VGPRs.  asm on purpose: with MFMA *builtins* in a kernel
+// whose asm names AGPRs, hipcc moves the accumulators into AGPRs of its own choosing (the ones this file's loads are
+// in flight to).  hipcc's hazard recogniser does not look inside: callers drain before a VALU read of `acc`.
 template <typename T>
-struct Mfma16;
-template <>
-struct Mfma16<BF16> {
-    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <>
-struct Mfma16<F16> {
-    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
+__device__ __forceinline__ void mfma16_acc(f32x4& acc, const u32x4& a, const u32x4& b) {
+    if constexpr (std::is_same<T, BF16>::value) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_g;
 __device__ __forceinline__ u32x2 lds_tr16_g(unsigned lds_byte_addr) {
@@ -62,11 +66,39 @@ __device__ __forceinline__ void dma16_g(u32x4 rsrc, unsigned voff, unsigned soff
                  : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
                  : "memory");
 }
-// 16 B per lane into registers, same bounds check
-__device__ __forceinline__ u32x4 load16_g(u32x4 rsrc, unsigned voff, unsigned soff) {
-    u32x4 r;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-    return r;
+// K fragment I of the two register sets (set = I / 8, 16-key half = (I / 4) & 1, 32-dim chunk = I & 3) in a[4I : 4I+3]
+template <int I>
+struct KReg;
+#define HYD_KREG(I, A, B, C, E)                                                                                          \
+    template <>                                                                                                          \
+    struct KReg<I> {                                                                                                     \
+        template <int OFF> /* 16 B per lane, bounds-checked: rows past the resource's end read as zero */                \
+        static __device__ __forceinline__ void load(u32x4 rsrc, unsigned voff, unsigned soff) {                          \
+            asm volatile("buffer_load_dwordx4 a[" #A ":" #E "], %0, %1, %2 offen offset:%3" ::"v"(voff), "s"(rsrc),      \
+                         "s"(soff), "i"(OFF)                                                                             \
+                         : "memory", "a" #A, "a" #B, "a" #C, "a" #E);                                                    \
+        }                                                                                                                \
+        template <typename T, bool FIRST> /* s (+)= K_frag . q^T */                                                      \
+        static __device__ __forceinline__ void qk(f32x4& s, const u32x4& q) {                                            \
+            constexpr bool BF = std::is_same<T, BF16>::value;                                                            \
+            if constexpr (BF && FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[" #A ":" #E "], %1, 0" : "=&v"(s) : "v"(q)); \
+            else if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[" #A ":" #E "], %1, %0" : "+v"(s) : "v"(q));     \
+            else if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, a[" #A ":" #E "], %1, 0" : "=&v"(s) : "v"(q));   \
+            else asm volatile("v_mfma_f32_16x16x32_f16 %0, a[" #A ":" #E "], %1, %0" : "+v"(s) : "v"(q));                        \
+        }                                                                                                                \
+    };
+HYD_KREG(0, 0, 1, 2, 3) HYD_KREG(1, 4, 5, 6, 7) HYD_KREG(2, 8, 9, 10, 11) HYD_KREG(3, 12, 13, 14, 15)
+HYD_KREG(4, 16, 17, 18, 19) HYD_KREG(5, 20, 21, 22, 23) HYD_KREG(6, 24, 25, 26, 27) HYD_KREG(7, 28, 29, 30, 31)
+HYD_KREG(8, 32, 33, 34, 35) HYD_KREG(9, 36, 37, 38, 39) HYD_KREG(10, 40, 41, 42, 43) HYD_KREG(11, 44, 45, 46, 47)
+HYD_KREG(12, 48, 49, 50, 51) HYD_KREG(13, 52, 53, 54, 55) HYD_KREG(14, 56, 57, 58, 59) HYD_KREG(15, 60, 61, 62, 63)
+#undef HYD_KREG
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for_g(F&& f) {
+    if constexpr (N > 0) {
+        static_for_g<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
 }
 
 // symmetric all-reduce over the 4 lanes {l, l^16, l^32, l^48} (same query row, the 4 key groups)
@@ -94,17 +126,19 @@ __device__ __forceinline__ float quad_sum(float x) {
 // (m, l, O) merged through LDS at the end -- for shapes with too few units to fill the chip with one wave each (C3: 1024
 // units on 256 CUs, C5: 2048), where nothing but more waves hides the per-step load latency.
 template <typename T, int D, int WPU>
-__global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(WPU == 4 ? 2 : 4, WPU == 4 ? 2 : 4))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+__global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int RB = D * 2;        // bytes per K/V row
     constexpr int NCH = D / 32;      // 32-dim chunks of the QK^T contraction
     constexpr int NDB = D / 16;      // 16-wide d blocks of O^T
     constexpr int RPI = 1024 / RB;   // V rows per DMA instruction
     constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key V tile
-    __shared__ __attribute__((aligned(1024))) char vtiles[WPU][32 * RB];  // 32 * RB = 16 rows * D floats: reused by the merge
-    __shared__ float mlx[WPU][2][16];
+    constexpr int TILE = 32 * RB;    // bytes of one 32-key V tile (= 16 rows * D floats: reused by the merge)
+    constexpr int NLD = 2 * NCH + NVD;  // vector-memory instructions per step (K fragments + V DMA)
+    __shared__ __attribute__((aligned(1024))) char vtiles[WPU][2][TILE];
+    __shared__ float mlx[WPU][4][16];
     const int wave = WPU == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    char* vtile = vtiles[wave];
+    char* vtile = vtiles[wave][0];
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g4 = lane >> 4;
@@ -162,32 +196,47 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(WPU ==
     for (int db = 0; db < NDB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     const float sc = a.scale_log2e;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    for (int key0 = wave * 32; key0 < len; key0 += 32 * WPU) {
-        // all loads of the step first (K to registers, V to LDS), one wait; other waves of the CU hide the latency
-        const unsigned ksoff = (unsigned)key0 * k_ts2, vsoff = (unsigned)key0 * v_ts2;
-        u32x4 kf[2][NCH];
+    // ---- prefix partials (attention.py:21-43) are dealt to the unit's waves: wave w folds partials w, w + WPU, ... into
+    // its own (m, l, O) state after its keys -- a normalised partial (O_p, lse_p) IS the state (m = lse_p * log2 e, l = 1,
+    // O = O_p) -- and the merge of the waves then combines everything; no partial is left for the final epilogue.  The
+    // wave's first partial, when it is a 16-bit one (the usual single unsplit prefix level), is fetched here, under the
+    // K/V stream.  (These loads are older than every asm-issued one: the counted waits of the loop stay exact.)
+    const int np = a.n_partials;
+    const bool pre = wave < np && !a.partials[wave].is_f32;
+    float pre_lse = -INFINITY;
+    u32x2 pre_u[NDB];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+    for (int db = 0; db < NDB; ++db) pre_u[db] = u32x2{0u, 0u};
+    if (pre) {
+        pre_lse = a.partials[wave].lse[ridx];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) kf[h][c] = load16_g(krs, kvoff + (unsigned)h * 16u * k_ts2 + 64u * c, ksoff);
-#pragma unroll
-        for (int i = 0; i < NVD; ++i) dma16_g(vrs, vvoff[i], vsoff, vt0 + i * 1024);
-        // wait for everything; names the K registers so that no MFMA is scheduled above the wait
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1])
-                     :
-                     : "memory");
-        if constexpr (NCH == 4)
-            asm volatile("" : "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+        for (int db = 0; db < NDB; ++db)
+            pre_u[db] = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.partials[wave].out) + ridx * D + 16 * db + 4 * g4);
+    }
 
-        f32x4 s0 = zero4, s1 = zero4;
+    // all vector-memory instructions of one step: K fragments into register set BUF, V tile into LDS tile BUF
+    auto issue = [&](auto BUF_, int key0) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(BUF_)::value;
+        const unsigned ks0 = (unsigned)key0 * k_ts2, ks1 = ks0 + 16u * k_ts2, vsoff = (unsigned)key0 * v_ts2;
+        static_for_g<NCH>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            KReg<BUF * 8 + c>::template load<64 * c>(krs, kvoff, ks0);
+            KReg<BUF * 8 + 4 + c>::template load<64 * c>(krs, kvoff, ks1);
+        });
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            s0 = Mfma16<T>::run(kf[0][c], qf[c], s0);
-            s1 = Mfma16<T>::run(kf[1][c], qf[c], s1);
-        }
+        for (int i = 0; i < NVD; ++i) dma16_g(vrs, vvoff[i], vsoff, vt0 + BUF * TILE + i * 1024);
+    };
+    auto step = [&](auto BUF_, int key0) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(BUF_)::value;
+        f32x4 s0, s1;
+        static_for_g<NCH>([&](auto C_) {
+            constexpr int c = decltype(C_)::value;
+            KReg<BUF * 8 + c>::template qk<T, c == 0>(s0, qf[c]);
+            KReg<BUF * 8 + 4 + c>::template qk<T, c == 0>(s1, qf[c]);
+        });
+        // the MFMAs above are asm: hipcc's hazard recogniser does not see that their results need the pipeline drained
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s0), "+v"(s1));
         // scores of this lane: keys key0 + 4 g4 + i (s0) and key0 + 16 + 4 g4 + i (s1), query row l15
         float p[8];
         const int kb = key0 + 4 * g4;
@@ -212,16 +261,98 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(WPU ==
         const u32x4 pf = {TR::pack2(p[0], p[1]), TR::pack2(p[2], p[3]), TR::pack2(p[4], p[5]), TR::pack2(p[6], p[7])};
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-            const u32x2 t0 = lds_tr16_g(vaddr[db]);
-            const u32x2 t1 = lds_tr16_g(vaddr[db] + 16 * RB);
+            const u32x2 t0 = lds_tr16_g(vaddr[db] + BUF * TILE);
+            const u32x2 t1 = lds_tr16_g(vaddr[db] + BUF * TILE + 16 * RB);
             const u32x4 vf = {t0[0], t0[1], t1[0], t1[1]};
-            o[db] = Mfma16<T>::run(vf, pf, o[db] * alpha);
+            o[db] *= alpha;
+            mfma16_acc<T>(o[db], vf, pf);
         }
-        // the next step's DMA overwrites the tile: every transposing read above has returned (the MFMAs consumed them)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // tile BUF is overwritten by the DMA of step i+2: every transposing read above has returned; and the accumulators
+        // are read by plain VALU code next (the rescale of the next step, the epilogue): drain the matrix pipeline
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    };
+    {
+        using std::integral_constant;
+        constexpr int stride = 32 * WPU;
+        const int k_first = wave * 32;
+        const int nst = len > k_first ? (len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
+        auto key_of = [&](int j) { return k_first + j * stride; };
+        if (nst > 0) {
+            issue(integral_constant<int, 0>{}, key_of(0));
+            for (int j = 0;;) {
+                bool more = j + 1 < nst;
+                if (more) {
+                    issue(integral_constant<int, 1>{}, key_of(j + 1));
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");  // step j landed, step j+1 in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                step(integral_constant<int, 0>{}, key_of(j));
+                if (!more) break;
+                ++j;
+                more = j + 1 < nst;
+                if (more) {
+                    issue(integral_constant<int, 0>{}, key_of(j + 1));
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                step(integral_constant<int, 1>{}, key_of(j));
+                if (!more) break;
+                ++j;
+            }
+        }
+    }
+
+    // ---- fold this wave's share of the prefix partials ------------------------------------------------------------
+    const float m_s = m_run, l_s = l_run;  // the suffix-only state: the LSE output is the suffix pass's own
+    auto fold = [&](float lse_p, const f32x4(&x)[NDB]) __attribute__((always_inline)) {
+        const float m_p = lse_p * 1.4426950408889634f;
+        const float mf = fmaxf(m_run, m_p);
+        const float ms = (mf == -INFINITY) ? 0.f : mf;
+        const float a1 = fast_exp2(m_run - ms), a2 = fast_exp2(m_p - ms);
+        l_run = l_run * a1 + a2;
+        m_run = mf;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[db] = o[db] * a1 + x[db] * a2;
+    };
+    auto widen = [&](const u32x2(&u)[NDB], f32x4(&x)[NDB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) x[db] = f32x4{TR::lo(u[db][0]), TR::hi(u[db][0]), TR::lo(u[db][1]), TR::hi(u[db][1])};
+    };
+    auto fetch = [&](const PartialDev& pd, f32x4(&x)[NDB]) __attribute__((always_inline)) {
+        if (pd.is_f32) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                x[db] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(pd.out) + ridx * D + 16 * db + 4 * g4);
+        } else {
+            u32x2 u[NDB];
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                u[db] = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(pd.out) + ridx * D + 16 * db + 4 * g4);
+            widen(u, x);
+        }
+    };
+    if (pre) {
+        f32x4 x[NDB];
+        widen(pre_u, x);
+        fold(pre_lse, x);
+    }
+    for (int i = wave + (pre ? WPU : 0); i < np; i += 2 * WPU) {
+        // two partials per round trip: their lse values and 2 * D/16 row pieces are all requested before the first use
+        const bool two = i + WPU < np;
+        const int i1 = two ? i + WPU : i;
+        const float lse0 = a.partials[i].lse[ridx];
+        const float lse1 = two ? a.partials[i1].lse[ridx] : -INFINITY;
+        f32x4 x0[NDB], x1[NDB];
+        fetch(a.partials[i], x0);
+        fetch(a.partials[i1], x1);
+        fold(lse0, x0);
+        fold(lse1, x1);
     }
 
     // ---- merge the WPU waves of the unit: every wave leaves (m, l, O^T) in its own tile, wave 0 folds them -------
+    float ms_run = m_s, ls_run = l_s;
     if constexpr (WPU > 1) {
         float* mine = reinterpret_cast<float*>(vtile);  // [16 rows][D]: O (unnormalised)
         // lane (row l15, key group g4) holds O^T[d = 16 db + 4 g4 + i][row l15] in o[db][i]; m / l are equal over g4
@@ -231,73 +362,38 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(WPU ==
         if (g4 == 0) {
             mlx[wave][0][l15] = m_run;
             mlx[wave][1][l15] = l_run;
+            mlx[wave][2][l15] = m_s;
+            mlx[wave][3][l15] = l_s;
         }
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
         for (int w = 1; w < WPU; ++w) {
-            const float* oth = reinterpret_cast<const float*>(vtiles[w]);
+            const float* oth = reinterpret_cast<const float*>(vtiles[w][0]);
             const float m2 = mlx[w][0][l15], l2 = mlx[w][1][l15];
             const float mf = fmaxf(m_run, m2);
             const float ms = (mf == -INFINITY) ? 0.f : mf;
             const float a1 = fast_exp2(m_run - ms), a2 = fast_exp2(m2 - ms);
             l_run = l_run * a1 + l2 * a2;
             m_run = mf;
+            const float m3 = mlx[w][2][l15], l3 = mlx[w][3][l15];
+            const float mg = fmaxf(ms_run, m3);
+            const float mgs = (mg == -INFINITY) ? 0.f : mg;
+            ls_run = ls_run * fast_exp2(ms_run - mgs) + l3 * fast_exp2(m3 - mgs);
+            ms_run = mg;
 #pragma unroll
             for (int db = 0; db < NDB; ++db) o[db] = o[db] * a1 + *reinterpret_cast<const f32x4*>(oth + l15 * D + 16 * db + 4 * g4) * a2;
+            asm volatile("" ::: "memory");  // one wave's tile at a time: hoisting all three costs 96 registers
         }
     }
 
-    // ---- epilogue: normalise, merge with the prefix partials (attention.py:21-43), store ---------------------
+    // ---- epilogue: normalise and store (the prefix partials are already in) -----------------------------------------
     if (!rvalid) return;
+    if (a.lse && g4 == 0) a.lse[ridx] = ls_run > 0.f ? ms_run * kLn2 + __logf(ls_run) : -INFINITY;
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    const float lse_s = l_run > 0.f ? m_run * kLn2 + __logf(l_run) : -INFINITY;
-    if (a.lse && g4 == 0) a.lse[ridx] = lse_s;
-    // partials are read four at a time with clamped indices: a batch's loads are all in flight together (a split-KV
-    // prefix level hands over up to 16 fp32 slices)
-    const int np = a.n_partials;
-    float M = lse_s;
-    for (int i = 0; i < np; i += 4) {
-        float lv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lv[j] = a.partials[min(i + j, np - 1)].lse[ridx];
-        M = fmaxf(fmaxf(M, fmaxf(lv[0], lv[1])), fmaxf(lv[2], lv[3]));
-    }
-    const float Ms = (M == -INFINITY) ? 0.f : M;
-    const float ws = np ? __expf(lse_s - Ms) : 1.0f;
-    float den = ws;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) o[db] *= inv * ws;
-    for (int i = 0; i < np; i += 2) {
-        // two partials per step: their 2 * D/16 row pieces are all requested before the first one is used
-        const int i1 = min(i + 1, np - 1);
-        const float w0 = __expf(a.partials[i].lse[ridx] - Ms);
-        const float w1 = i + 1 < np ? __expf(a.partials[i1].lse[ridx] - Ms) : 0.f;
-        den += w0 + w1;
-        f32x4 x0[NDB], x1[NDB];
-        auto fetch = [&](const PartialDev& pd, f32x4(&x)[NDB]) __attribute__((always_inline)) {
-            if (pd.is_f32) {
-#pragma unroll
-                for (int db = 0; db < NDB; ++db)
-                    x[db] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(pd.out) + ridx * D + 16 * db + 4 * g4);
-            } else {
-                u32x2 u[NDB];
-#pragma unroll
-                for (int db = 0; db < NDB; ++db)
-                    u[db] = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(pd.out) + ridx * D + 16 * db + 4 * g4);
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) x[db] = f32x4{TR::lo(u[db][0]), TR::hi(u[db][0]), TR::lo(u[db][1]), TR::hi(u[db][1])};
-            }
-        };
-        fetch(a.partials[i], x0);
-        fetch(a.partials[i1], x1);
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) o[db] += x0[db] * w0 + x1[db] * w1;
-    }
-    const float dinv = a.n_partials ? (den > 0.f ? 1.0f / den : 0.f) : 1.0f;
 #pragma unroll
     for (int db = 0; db < NDB; ++db) {
-        const f32x4 x = o[db] * dinv;
+        const f32x4 x = o[db] * inv;
         const u32x2 pk = {TR::pack2(x[0], x[1]), TR::pack2(x[2], x[3])};
         *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.out) + ridx * D + 16 * db + 4 * g4) = pk;
     }
@@ -320,7 +416,10 @@ static int launch_gqa_t(const SuffixArgs& a, hipStream_t s) {
     const int chunks = (a.rows + 15) / 16;
     // shapes only: fewer than 4 one-wave units per CU (measured: B=32, 8/1 heads, 1152 keys 48 -> 31 us; at 1024 and
     // 2048 units -- C3, C5 -- one wave per unit is as fast or faster), and enough keys to deal out
-    const bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len >= 128;
+    bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len >= 128;
+#ifdef HYD_ABLATION_BUILD
+    if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
+#endif
     dim3 grid(a.B, a.Hkv, chunks);
     if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1>), grid, dim3(64), 0, s, a);

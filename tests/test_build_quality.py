@@ -14,8 +14,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # file -> (max VGPRs per kernel matching the regex)
 LIMITS = {
     "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512)],   # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs)
-    # 1 wave per unit: 4 waves / SIMD; the 4-waves-per-unit variant only runs when the grid cannot fill the chip anyway
-    "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256), (r"suffix_attn_gqa_kernelINS_\w+ELi\d+ELi1EE", 128)],
+    # 2 waves / SIMD (two 8-KiB V tiles per wave bound the occupancy anyway); the count includes the 64 AGPRs of the K sets
+    "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256)],
     "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1E", 80)],  # MHA decode: 6 waves / SIMD
     "combine.hip": [(r"combine", 128)],
     "rope_append.hip": [(r"rope_append", 128)],
@@ -78,3 +78,33 @@ def test_prefix_kernel_owns_its_accumulator_registers():
     counts = [int(x) for x in re.findall(r"\.agpr_count:\s+(\d+)", out)]
     assert counts and min(counts) >= 160, counts
     assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and "a[128:131]" in out
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_gqa_suffix_kernel_owns_its_k_registers_while_loads_are_in_flight():
+    """suffix_attn_gqa.hip loads the K fragments of step i+1 into literal AGPRs (a[0:63]) while step i is computed.
+    Between the first and the last asm statement that names an AGPR (the pipelined loop) no compiler-generated
+    instruction may name one: hipcc sees those registers as free between two clobbering statements and could park a
+    value where a load is about to land.  (Outside the loop -- the 4-wave merge -- it may use them.)"""
+    out = _device_asm("suffix_attn_gqa.hip")
+    kernels, cur, inasm = {}, None, False
+    for n, line in enumerate(out.splitlines()):
+        t = line.strip()
+        m = re.match(r"^(_ZN3hyd\w+):", t)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = dict(asm=[], comp=[])
+        if cur is None:
+            continue
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
+        elif t and not t.startswith((";", ".", "//")) and re.search(r"\ba\[?\d", t.split(";")[0]):
+            kernels[cur]["asm" if inasm else "comp"].append((n, t))
+    assert len(kernels) == 8, sorted(kernels)
+    for name, v in kernels.items():
+        assert v["asm"], name
+        lo, hi = v["asm"][0][0], v["asm"][-1][0]
+        inside = [t for n, t in v["comp"] if lo <= n <= hi]
+        assert not inside, f"{name}: compiler-generated AGPR use inside the pipelined loop: {inside[:4]}"

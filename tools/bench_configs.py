@@ -36,7 +36,7 @@ CONFIGS = [
 ]
 
 
-def timed(fn, iters, flush=None):
+def timed(fn, iters, flush=None, clean=None):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -44,6 +44,8 @@ def timed(fn, iters, flush=None):
     for _ in range(iters):
         if flush is not None:
             flush.add_(1)
+        if clean is not None:
+            clean.sum()  # read-only pass: evicts the flush's dirty lines, whose write-back the timed call would pay
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
@@ -63,14 +65,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="run only the configs whose name contains this (e.g. 'C5')")
+    ap.add_argument("--no-baseline", action="store_true", help="skip the no-sharing leg (for kernel profiles)")
     a = ap.parse_args()
     flush = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=DEV)
+    clean = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=DEV)
     lines = [
-        "| config | hydragen us (back to back) | hydragen us (cache flushed) | no-sharing us (flushed) | speed-up | hydragen KV bytes | effective GB/s (flushed) |",
-        "|---|---|---|---|---|---|---|",
+        "Flushed = 512 MB written before every call (the reference's protocol); the write leaves up to 256 MB of dirty lines in",
+        "the Infinity Cache whose write-back lands in the timed call.  Cold = the same flush followed by a 512 MB read-only pass:",
+        "nothing of the call's data is cached and nothing is waiting to be written back.",
+        "",
+        "| config | hydragen us (back to back) | hydragen us (flushed) | hydragen us (cold) | no-sharing us (flushed) | speed-up (flushed) | hydragen KV bytes | effective GB/s (cold) |",
+        "|---|---|---|---|---|---|---|---|",
     ]
     g = torch.Generator(device=DEV).manual_seed(0)
     for name, B, levels, S, Hq, Hkv, D, dt in CONFIGS:
+        if a.only and a.only not in name:
+            continue
         r = lambda *s: torch.randn(*s, device=DEV, dtype=dt, generator=g)
         q, k, v = r(B, 1, Hq, D), r(B, S, Hkv, D), r(B, S, Hkv, D)
         sks, svs = [r(sb, P, Hkv, D) for sb, P in levels], [r(sb, P, Hkv, D) for sb, P in levels]
@@ -78,12 +89,13 @@ def main():
         hyd = lambda: hydragen_attention_nopad(q, k, v, sks, svs, seq_len=lens)
         hm, hs = timed(hyd, a.iters)
         fm, fs = timed(hyd, a.iters, flush)
+        cm, cs = timed(hyd, a.iters, flush, clean)
         e = q.element_size()
         kv_bytes = 2 * e * Hkv * D * (B * S + sum(sb * P for sb, P in levels)) + 2 * B * Hq * D * e
         ptot = sum(P for _, P in levels)
         ns_bytes = 2 * e * B * (ptot + S) * Hkv * D
         nm = ns = None
-        if ns_bytes < 150e9:
+        if ns_bytes < 150e9 and not a.no_baseline:
             try:
                 per = [B // sb for sb, _ in levels]
                 kt = torch.cat([sk.repeat_interleave(p, 0) for sk, p in zip(sks, per)] + [k], 1).contiguous()
@@ -96,7 +108,7 @@ def main():
         torch.cuda.empty_cache()
         sp = f"{nm / fm:5.1f}x" if nm else "n/a (KV > HBM budget)"
         nstr = fmt(nm, ns) if nm else f"({ns_bytes / 1e9:.0f} GB of KV)"
-        lines.append(f"| {name} | {fmt(hm, hs)} | {fmt(fm, fs)} | {nstr} | {sp} | {kv_bytes / 2**20:.0f} MiB | {kv_bytes / fm / 1e3:.0f} |")
+        lines.append(f"| {name} | {fmt(hm, hs)} | {fmt(fm, fs)} | {fmt(cm, cs)} | {nstr} | {sp} | {kv_bytes / 2**20:.0f} MiB | {kv_bytes / cm / 1e3:.0f} |")
         print(lines[-1], flush=True)
     txt = "\n".join(lines) + "\n"
     if a.out:
