@@ -39,8 +39,10 @@ namespace {
 // in flight to).  hipcc's hazard recogniser does not look inside: callers drain before a VALU read of `acc`.
 template <typename T>
 __device__ __forceinline__ void mfma16_acc(f32x4& acc, const u32x4& a, const u32x4& b) {
-    if constexpr (std::is_same<T, BF16>::value) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    // s_nop 1: the operands were just written by plain VALU code (the rescale of acc, the packed P); a VALU write
+    // followed by a matrix-core read of the same VGPR wants two wait states, which hipcc inserts only for its own MFMAs
+    if constexpr (std::is_same<T, BF16>::value) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_g;
