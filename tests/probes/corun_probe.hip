@@ -7,10 +7,14 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-template <bool BIG>
+template <int BIG>
 __global__ __launch_bounds__(256) void corun_kernel(float* out, int iters, int nvalu) {
     extern __shared__ char smem[];
-    if constexpr (BIG) asm volatile("" ::: "v250");  // allocate a 256-register wave, like a half-size prefix-pass variant would
+    // allocate a wave of a given register count, like a prefix-pass variant of that size would
+    if constexpr (BIG == 1) asm volatile("" ::: "v250");
+    if constexpr (BIG == 2) asm volatile("" ::: "v180");
+    if constexpr (BIG == 3) asm volatile("" ::: "v120");
+    if constexpr (BIG == 4) asm volatile("" ::: "v90");
     f32x16_t acc0 = {0}, acc1 = {0};
     bf16x8_t a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(i - 3); }
@@ -33,23 +37,27 @@ __global__ __launch_bounds__(256) void corun_kernel(float* out, int iters, int n
 }
 
 extern "C" int corun_launch(void* out, int iters, int nvalu, void* stream) {
-    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(corun_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess);
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(corun_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(corun_kernel<true>, dim3(256), dim3(256), 128 * 1024, (hipStream_t)stream, (float*)out, iters, nvalu);
+    hipLaunchKernelGGL(corun_kernel<1>, dim3(256), dim3(256), 128 * 1024, (hipStream_t)stream, (float*)out, iters, nvalu);
     return (int)hipGetLastError();
 }
 // the small variant (~50 registers, 16 KB of LDS): two of these fit on a CU many times over -- the control experiment
 extern "C" int corun_launch_small(void* out, int iters, int nvalu, void* stream) {
-    hipLaunchKernelGGL(corun_kernel<false>, dim3(256), dim3(256), 16 * 1024, (hipStream_t)stream, (float*)out, iters, nvalu);
+    hipLaunchKernelGGL(corun_kernel<0>, dim3(256), dim3(256), 16 * 1024, (hipStream_t)stream, (float*)out, iters, nvalu);
     return (int)hipGetLastError();
 }
 
-// any combination: big = 251 registers per wave or ~50; lds = bytes of dynamic LDS per workgroup
+// any combination: big = 0 / 4 / 3 / 2 / 1 -> ~50 / 91 / 121 / 181 / 251 registers per wave; lds = bytes of dynamic LDS per workgroup
 extern "C" int corun_launch_cfg(void* out, int iters, int nvalu, void* stream, int big, int lds) {
-    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(corun_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess) &&
-                       (hipFuncSetAttribute(reinterpret_cast<const void*>(corun_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess);
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(corun_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess) &&
+                       (hipFuncSetAttribute(reinterpret_cast<const void*>(corun_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess);
     (void)once;
-    if (big) hipLaunchKernelGGL(corun_kernel<true>, dim3(256), dim3(256), lds, (hipStream_t)stream, (float*)out, iters, nvalu);
-    else hipLaunchKernelGGL(corun_kernel<false>, dim3(256), dim3(256), lds, (hipStream_t)stream, (float*)out, iters, nvalu);
+    switch (big) {
+#define CORUN(N) case N: hipLaunchKernelGGL(corun_kernel<N>, dim3(256), dim3(256), lds, (hipStream_t)stream, (float*)out, iters, nvalu); break;
+        CORUN(1) CORUN(2) CORUN(3) CORUN(4)
+        default: hipLaunchKernelGGL(corun_kernel<0>, dim3(256), dim3(256), lds, (hipStream_t)stream, (float*)out, iters, nvalu);
+#undef CORUN
+    }
     return (int)hipGetLastError();
 }
