@@ -33,6 +33,7 @@ class PrefixParams(C.Structure):
         ("dtype", C.c_int32), ("B", C.c_int32), ("nq", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
         ("D", C.c_int32), ("sb", C.c_int32), ("kv_len", C.c_int32), ("max_q_len", C.c_int32),
         ("causal", C.c_int32), ("lse_layout", C.c_int32), ("num_splits", C.c_int32),
+        ("softmax_scale", C.c_float), ("reserved_", C.c_int32),
     ]
 
 
@@ -48,6 +49,7 @@ class SuffixParams(C.Structure):
         ("v_batch_stride", C.c_int64), ("v_tok_stride", C.c_int64), ("v_head_stride", C.c_int64),
         ("dtype", C.c_int32), ("B", C.c_int32), ("nq", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
         ("D", C.c_int32), ("kv_len", C.c_int32), ("n_partials", C.c_int32),
+        ("softmax_scale", C.c_float), ("reserved_", C.c_int32),
         ("partials", Partial * HYD_MAX_LEVELS),
     ]
 

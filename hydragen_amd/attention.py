@@ -18,6 +18,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from . import flash as _flash
 from ._lib import HYD_F32, HYD_LSE_BQH, HYD_MAX_LEVELS, DecodeParams
 from .flash import (
     _dtype_code, _lastdim_contig, _q_contig, _require_gpu, _stream, fill_suffix_params, prefix_attention,
@@ -123,6 +124,13 @@ def hydragen_attention(
         raise NotImplementedError(f"at most {HYD_MAX_LEVELS} shared levels")
 
     b, nq, hq, d = q.shape
+    dp = _flash.padded_head_dim(d)
+    if dp != d:  # zero-padded to the kernels' head dim, true scale (flash.py: "head dims other than ...")
+        pad = lambda t: _flash.pad_head_dim(t, dp)
+        with _flash.true_head_dim_scale(d):
+            out = hydragen_attention(pad(q), pad(k), pad(v), [pad(x) for x in shared_ks], [pad(x) for x in shared_vs],
+                                     shared_cu_seq_lens, shared_max_seq_lens, use_varlens, seq_lens)
+        return out[..., :d].contiguous()
     q = _q_contig(q)
     k, v = _lastdim_contig(k), _lastdim_contig(v)
     shared_ks = [_lastdim_contig(x) for x in shared_ks]
@@ -191,7 +199,7 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
     lib = _lib.load()
     b, nq, hq, d = q.shape
     out = torch.empty_like(q)
-    capturing = torch.cuda.is_current_stream_capturing()
+    capturing = torch.cuda.is_current_stream_capturing() or _flash._SCALE != 0.0  # padded temporaries: nothing to cache
     key = None
     if not capturing:  # a captured call keeps its scratch in the graph's private pool instead
         key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), q.device.index,

@@ -42,6 +42,16 @@ struct PrefixPlan {
     int g, per, row_blocks, nsplit, split_len, grid, qpg, wg_rows;
 };
 
+// softmax scale in base-2 exponent units: the caller's scale when it gives one, D^-0.5 otherwise
+float scale_log2e_of(float softmax_scale, int D) {
+    return (softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)D)) * kLog2e;
+}
+
+int check_scale(float s) {
+    if (!(s >= 0.f) || s > 1.0e4f) return fail(HYD_ERR_BAD_ARG, "softmax_scale %g (0 = head_dim^-0.5, or a positive finite scale)", (double)s);
+    return HYD_OK;
+}
+
 int check_common(int dtype, int B, int nq, int Hq, int Hkv, int D) {
     if (dtype != HYD_F16 && dtype != HYD_BF16) return fail(HYD_ERR_UNSUPPORTED, "dtype %d: only f16/bf16", dtype);
     if (D != 64 && D != 128) return fail(HYD_ERR_UNSUPPORTED, "head_dim %d: only 64 and 128 are implemented", D);
@@ -53,6 +63,7 @@ int check_common(int dtype, int B, int nq, int Hq, int Hkv, int D) {
 int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMaxSplits) {
     if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
     int rc = check_common(p->dtype, p->B, p->nq, p->Hq, p->Hkv, p->D);
+    if (!rc) rc = check_scale(p->softmax_scale);
     if (rc) return rc;
     if (p->sb <= 0) return fail(HYD_ERR_BAD_ARG, "sb %d", p->sb);
     if (p->kv_len < 0) return fail(HYD_ERR_BAD_ARG, "kv_len %d", p->kv_len);
@@ -160,7 +171,7 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->nsplit = pl.nsplit;
     a->split_len = pl.split_len;
     a->lse_q_stride = pl.qpg;
-    a->scale_log2e = (1.0f / sqrtf((float)p->D)) * kLog2e;
+    a->scale_log2e = scale_log2e_of(p->softmax_scale, p->D);
     a->dbg = dev_switch("HYD_DBG");  // timing-ablation kernel variants; always 0 in product builds
 }
 
@@ -236,6 +247,7 @@ int check_stride8(int64_t s, const char* name) {
 int check_suffix(const hyd_suffix_params* p, bool need_kv) {
     if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
     int rc = check_common(p->dtype, p->B, p->nq, p->Hq, p->Hkv, p->D);
+    if (!rc) rc = check_scale(p->softmax_scale);
     if (rc) return rc;
     if (p->kv_len < 0) return fail(HYD_ERR_BAD_ARG, "kv_len %d", p->kv_len);
     if ((rc = check_ptr_align(p->q, "q"))) return rc;
@@ -275,7 +287,7 @@ int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts
     a.kv_len = p->kv_len;
     a.rows = p->nq * a.g;
     a.units = p->B * p->Hkv;
-    a.scale_log2e = (1.0f / sqrtf((float)p->D)) * kLog2e;
+    a.scale_log2e = scale_log2e_of(p->softmax_scale, p->D);
     const size_t rows = (size_t)p->B * p->nq * p->Hq;
     int n = 0;
     for (int i = 0; i < n_parts; ++i) {
@@ -321,6 +333,7 @@ void level_to_prefix(const hyd_decode_params* p, int i, hyd_prefix_params* pp) {
     pp->Hq = s.Hq;
     pp->Hkv = s.Hkv;
     pp->D = s.D;
+    pp->softmax_scale = s.softmax_scale;
     pp->sb = lv.sb;
     pp->kv_len = lv.kv_len;
     pp->causal = 0;
@@ -351,7 +364,7 @@ int run_level_small(const hyd_prefix_params& pp, const PrefixPlan& pl, void* out
     a.B = pp.sb; a.nq = pl.qpg; a.Hq = pp.Hq; a.Hkv = pp.Hkv; a.g = pl.g; a.kv_len = pp.kv_len;
     a.rows = pl.qpg * pl.g;
     a.units = pp.sb * pp.Hkv;
-    a.scale_log2e = (1.0f / sqrtf((float)pp.D)) * kLog2e;
+    a.scale_log2e = scale_log2e_of(pp.softmax_scale, pp.D);
     const int rc = launch_suffix_gqa(a, pp.dtype, pp.D, s);
     return rc ? fail(HYD_ERR_LAUNCH, "small-level kernel launch failed: hip error %d", rc) : HYD_OK;
 }

@@ -66,6 +66,42 @@ def _q_contig(q: Tensor) -> Tensor:
     return q.contiguous()
 
 
+# ---- head dims other than the kernels' 64 / 128 -------------------------------------------------------------------
+# flash-attn takes any head_dim that is a multiple of 8 (flash.py:295-304 hands it whatever the model has).  The HIP
+# kernels are instantiated for 64 and 128; other multiples of 8 below 128 run zero-PADDED to the next of the two with
+# the TRUE head dim's softmax scale (hyd_*_params.softmax_scale): zero columns add nothing to q.k and produce zero
+# output columns, which are cut off again.  Functional, not fast: q, k and v are copied on every call -- a model with
+# such a head dim should keep its caches padded instead.
+_SCALE = 0.0  # forwarded to the C ABI by the marshalling helpers below; 0 = head_dim ** -0.5
+
+
+def padded_head_dim(d: int) -> int:
+    if d in (64, 128):
+        return d
+    if d <= 0 or d % 8 or d > 128:
+        raise NotImplementedError(f"head_dim {d}: multiples of 8 up to 128 are implemented")
+    return 64 if d < 64 else 128
+
+
+def pad_head_dim(t: Tensor, dp: int) -> Tensor:
+    return torch.nn.functional.pad(t, (0, dp - t.shape[-1]))
+
+
+class true_head_dim_scale:
+    """with true_head_dim_scale(d): every call marshalled inside uses softmax scale d ** -0.5."""
+
+    def __init__(self, d: int):
+        self.scale = float(d) ** -0.5
+
+    def __enter__(self):
+        global _SCALE
+        self.prev, _SCALE = _SCALE, self.scale
+
+    def __exit__(self, *exc):
+        global _SCALE
+        _SCALE = self.prev
+
+
 def prefix_attention(
     q: Tensor, k: Tensor, v: Tensor, *, sb: int, kv_len: int, group_stride: tuple[int, int],
     tok_stride: tuple[int, int], head_stride: tuple[int, int], B: int, nq: int, causal: bool,
@@ -97,6 +133,7 @@ def prefix_attention(
     p.causal = 1 if causal else 0
     p.lse_layout = lse_layout
     p.num_splits = num_splits
+    p.softmax_scale = _SCALE
     ws_bytes = lib.hyd_prefix_workspace_bytes(C.byref(p))
     ws = None
     if ws_bytes:
@@ -120,6 +157,11 @@ def flash_attention(q: Tensor, k: Tensor, v: Tensor, causal: bool = False) -> tu
     assert k.shape == v.shape, f"{k.shape} {v.shape}"
     b, sq, hq, d = q.shape
     assert k.shape[0] == b and k.shape[3] == d, f"{q.shape} {k.shape}"
+    dp = padded_head_dim(d)
+    if dp != d:
+        with true_head_dim_scale(d):
+            out, lse = flash_attention(pad_head_dim(q, dp), pad_head_dim(k, dp), pad_head_dim(v, dp), causal)
+        return out[..., :d].contiguous(), lse
     q = _q_contig(q)
     k, v = _lastdim_contig(k), _lastdim_contig(v)
     return prefix_attention(
@@ -148,6 +190,12 @@ def flash_attention_varlen(
     assert cu_seqlens_q.shape == cu_seqlens_k.shape
     nseq = cu_seqlens_q.shape[0] - 1
     tq, hq, d = q.shape
+    dp = padded_head_dim(d)
+    if dp != d:
+        with true_head_dim_scale(d):
+            out, lse = flash_attention_varlen(pad_head_dim(q, dp), pad_head_dim(k, dp), pad_head_dim(v, dp), cu_seqlens_q,
+                                              cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal)
+        return out[..., :d].contiguous(), lse
     q = _q_contig(q)
     k, v = _lastdim_contig(k), _lastdim_contig(v)
     return prefix_attention(
@@ -169,6 +217,7 @@ def fill_suffix_params(p: SuffixParams, q: Tensor, k: Tensor, v: Tensor, seq_len
     p.dtype = _dtype_code(q)
     p.B, p.nq, p.Hq, p.Hkv, p.D = b, nq, hq, k.shape[2], d
     p.kv_len = k.shape[1]
+    p.softmax_scale = _SCALE
     keep = None
     if seq_len is not None:
         assert seq_len.shape == (b,), f"{seq_len.shape}"
@@ -200,6 +249,12 @@ def flash_attention_seqlen(raw_q: Tensor, raw_k: Tensor, raw_v: Tensor, seq_len=
     assert raw_q.shape[-1] == raw_k.shape[-1], (
         f"Keys have head dim {raw_k.shape[-1]} but queries have head dim {raw_q.shape[-1]}"
     )
+    d = raw_q.shape[-1]
+    dp = padded_head_dim(d)
+    if dp != d:
+        with true_head_dim_scale(d):
+            out, lse = flash_attention_seqlen(pad_head_dim(raw_q, dp), pad_head_dim(raw_k, dp), pad_head_dim(raw_v, dp), seq_len)
+        return out[..., :d].contiguous(), lse
     lib = _lib.load()
     q = _q_contig(raw_q)
     k, v = _lastdim_contig(raw_k), _lastdim_contig(raw_v)

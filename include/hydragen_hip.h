@@ -44,7 +44,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
 #define HYD_API __attribute__((visibility("default")))
 
-#define HYD_VERSION 200 /* 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
+#define HYD_VERSION 201 /* 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
 #define HYD_MAX_LEVELS 8
 
 enum {
@@ -88,6 +88,9 @@ typedef struct hyd_prefix_params {
     int32_t causal;     /* 0 | 1 (bottom-right aligned: query i sees keys j <= i + kv - nq)    */
     int32_t lse_layout; /* HYD_LSE_BQH | HYD_LSE_BHQ                                           */
     int32_t num_splits; /* split-KV factor; 0 = choose from shapes                             */
+    float softmax_scale; /* 0 = D^-0.5 (what the reference always uses, flash.py:295-304); > 0: that
+                          * scale -- lets a caller run a zero-padded head dim with the true one's scale */
+    int32_t reserved_;
 } hyd_prefix_params;
 
 HYD_API size_t hyd_prefix_workspace_bytes(const hyd_prefix_params* p);
@@ -121,6 +124,8 @@ typedef struct hyd_suffix_params {
     int32_t B, nq, Hq, Hkv, D;
     int32_t kv_len;             /* allocated keys per sequence (Mk); lengths are clamped to it */
     int32_t n_partials;         /* entries used in partials[]                                  */
+    float softmax_scale;        /* 0 = D^-0.5; > 0: that scale (hyd_decode_attn_fused applies it to    */
+    int32_t reserved_;          /*   every level as well)                                              */
     hyd_partial partials[HYD_MAX_LEVELS];
 } hyd_suffix_params;
 
