@@ -198,3 +198,14 @@ def test_product_sources_never_touch_the_oracle():
             list((REPO / "hydragen_amd").rglob("*.h")):
         txt = path.read_text()
         assert "oracle" not in txt.replace("no CPU oracle", "").replace("or the CPU oracle", ""), path
+
+
+def test_head_dim_padding_rule():
+    """Which head dims the Python mirrors accept (hydragen_amd/flash.py): 64 / 128 natively, other multiples of 8 up to 128
+    padded to the next of the two, everything else refused like an unsupported shape."""
+    from hydragen_amd.flash import padded_head_dim
+
+    assert [padded_head_dim(d) for d in (8, 56, 64, 72, 80, 96, 120, 128)] == [64, 64, 64, 128, 128, 128, 128, 128]
+    for d in (0, 4, 100, 136, 256):
+        with pytest.raises(NotImplementedError):
+            padded_head_dim(d)
