@@ -170,6 +170,7 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->wg_rows = pl.wg_rows;
     a->nsplit = pl.nsplit;
     a->split_len = pl.split_len;
+    a->vgrid = pl.grid;
     a->lse_q_stride = pl.qpg;
     a->scale_log2e = scale_log2e_of(p->softmax_scale, p->D);
     a->dbg = dev_switch("HYD_DBG");  // timing-ablation kernel variants; always 0 in product builds
@@ -180,6 +181,7 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
 int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
 #ifdef HYD_ABLATION_BUILD
     if (dev_switch("HYD_PREFIX_PL")) return launch_prefix_pl(a, dtype, D, causal, grid, s);  // round-1 kernel, A/B only
+    if (const int np = dev_switch("HYD_PREFIX_PERSIST")) grid = grid < np ? grid : np;
 #endif
     return launch_prefix_w64(a, dtype, D, causal, grid, s);
 }

@@ -21,6 +21,7 @@ struct PrefixArgs {
     int32_t kv_len;
     int32_t lse_q_stride;  // BHQ layout: query tokens per group
     int32_t row_blocks, nsplit, split_len;
+    int32_t vgrid;    // units = sb * Hkv * nsplit * row_blocks; the launch grid may be smaller (persistent workgroups)
     int32_t wg_rows;  // query rows per workgroup: 128, or 256 (pipelined kernel, D = 128, large row counts)
     int32_t lse_layout, out_f32;
     float scale_log2e;

@@ -459,7 +459,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ABL: development-only timing ablations (bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
 // bit4 no barrier in the loop, bit5 no exp2, bit6 no element phase, bit7 no row sums / pack); only ABL = 0 ships.
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
-__global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a) {
+__device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
     constexpr int QB = 2;                // 32-row query blocks per wave
     constexpr int RB = D * 2;            // bytes per K/V row
@@ -470,7 +470,6 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
     constexpr int NLB = BROWS * RB / 1024 / 4;                // DMA instructions per wave per tensor per iteration
     constexpr int RPI = 1024 / RB;                            // rows per DMA instruction
     static_assert(NLB >= 1, "every wave issues at least one DMA instruction per tensor and iteration");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RING_BYTES = (KG == 2 ? 512 : 256) * RB;
     float* mlbuf = reinterpret_cast<float*>(smem + RING_BYTES);  // [4 waves][QB][2][64] (KG = 2 merge)
 
@@ -483,7 +482,11 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
         }
     };
     stampk(0);
-    const int tid = threadIdx.x;
+    // Opaque per unit: a persistent workgroup calls this in a loop, and everything derived from the lane index is
+    // loop-invariant there -- hoisted out of the unit loop it would stay live across the whole pipeline and push the
+    // allocation past 256 VGPRs (hipcc then parks values in AGPRs, which the asm statements own).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = KG == 2 ? wave >> 1 : 0;   // key half of every 128-key tile this wave computes on
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- which (group, kv head, split, row block) ------------------------------------------
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int lin = xcd_remap(vblock, vgrid);
     const int rb = lin % a.row_blocks;
     int t_ = lin / a.row_blocks;
     const int sp = t_ % a.nsplit;
@@ -1038,6 +1041,18 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
             for (int q_ = 1; q_ < 6; ++q_) tv = lane == q_ ? tst[q_] : tv;
             reinterpret_cast<unsigned*>(a.lse)[(size_t)a.B * a.nq * a.Hq + wave * 8 + lane] = tv;
         }
+    }
+}
+
+// One workgroup per unit (grid == a.vgrid), or -- when the caller asks for fewer workgroups than units -- persistent
+// workgroups that walk the units with a stride of the grid: how the shared phase is confined to a part of the chip
+// while the unique phase streams on the rest of it (hyd_decode_params.aux_stream).
+template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
+__global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int vb = blockIdx.x; vb < a.vgrid; vb += gridDim.x) {
+        prefix_unit_w64<T, D, CAUSAL, KG, ABL>(a, vb, a.vgrid, smem);
+        if (vb + (int)gridDim.x < a.vgrid) __syncthreads();  // the unit's LDS merge buffers are the next unit's rings
     }
 }
 
