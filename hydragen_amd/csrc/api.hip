@@ -265,8 +265,8 @@ int check_suffix(const hyd_suffix_params* p, bool need_kv) {
     return HYD_OK;
 }
 
-int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts, hipStream_t s) {
-    SuffixArgs a;
+void fill_suffix_args(const hyd_suffix_params* p, SuffixArgs* ap) {
+    SuffixArgs& a = *ap;
     memset(&a, 0, sizeof(a));
     a.q = p->q;
     a.k = p->k;
@@ -290,6 +290,11 @@ int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts
     a.rows = p->nq * a.g;
     a.units = p->B * p->Hkv;
     a.scale_log2e = scale_log2e_of(p->softmax_scale, p->D);
+}
+
+int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts, hipStream_t s) {
+    SuffixArgs a;
+    fill_suffix_args(p, &a);
     const size_t rows = (size_t)p->B * p->nq * p->Hq;
     int n = 0;
     for (int i = 0; i < n_parts; ++i) {
@@ -311,6 +316,15 @@ int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts
     if ((int64_t)p->kv_len * p->k_tok_stride * 2 >= (1ll << 31) || (int64_t)p->kv_len * p->v_tok_stride * 2 >= (1ll << 31))
         return fail(HYD_ERR_UNSUPPORTED, "unique K/V of one sequence spans >= 2 GiB (32-bit in-sequence offsets)");
     if (p->Hkv > 4 * 65535 || a.rows > 8 * 65535) return fail(HYD_ERR_UNSUPPORTED, "too many kv heads / query rows for the suffix grid");
+#ifdef HYD_ABLATION_BUILD
+    if (const int wgs = dev_switch("HYD_STREAM_WGS")) {  // the co-run kernel's streaming role alone, persistent, wgs workgroups
+        if (p->D == 128 && ((a.rows == 1 && a.g == 1) || dev_switch("HYD_STREAM_NBUF") == 100)) {
+            const int upi = dev_switch("HYD_CORUN_UPI") ? dev_switch("HYD_CORUN_UPI") : 8;
+            const int rc = launch_suffix_stream_dev(a, p->dtype, wgs, upi, dev_switch("HYD_STREAM_NBUF"), s);
+            return rc ? fail(HYD_ERR_LAUNCH, "stream kernel launch failed: hip error %d", rc) : HYD_OK;
+        }
+    }
+#endif
     int rc = launch_suffix(a, p->dtype, p->D, s);
     return rc ? fail(HYD_ERR_LAUNCH, "suffix kernel launch failed: hip error %d", rc) : HYD_OK;
 }
@@ -374,6 +388,24 @@ int run_level_small(const hyd_prefix_params& pp, const PrefixPlan& pl, void* out
 // The suffix epilogue merges at most kMaxCombine partials, so the levels of one decode call share that budget:
 // each level may cut its keys into at most kMaxCombine / n_levels slices (>= 8 with HYD_MAX_LEVELS = 8).
 int level_split_cap(int n_levels) { return n_levels > 0 ? kMaxCombine / n_levels : kMaxSplits; }
+
+// Co-run (corun_attn.hip): one shared level, one query row per (sequence, kv head), the 128-row prefix instantiation.
+// Scratch: two fp32 partials (out + lse each) and the 1 KiB queue block.
+size_t corun_ws_bytes(size_t rows, int D) {
+    return 2 * (align_up(rows * D * 4, 256) + align_up(rows * 4, 256)) + kCorunQueueBytes;
+}
+
+bool corun_shapes_ok(const hyd_decode_params* p, const hyd_prefix_params& pp, const PrefixPlan& pl) {
+    const hyd_suffix_params& s = p->suffix;
+    return p->n_levels == 1 && s.D == 128 && s.nq == 1 && s.Hq == s.Hkv && s.kv_len > 0 && !pp.cu_seqlens_k && pl.nsplit == 1 &&
+           pl.wg_rows == 128 && (int64_t)s.kv_len * (s.k_tok_stride > s.v_tok_stride ? s.k_tok_stride : s.v_tok_stride) * 2 < ((int64_t)1 << 31);
+}
+
+// shapes-only policy: when the one-launch co-run form is used instead of prefix pass -> suffix pass
+bool corun_wanted(const hyd_decode_params* p, const hyd_prefix_params& pp, const PrefixPlan& pl) {
+    if (p->phase != HYD_PHASE_ALL || !corun_shapes_ok(p, pp, pl)) return false;
+    return dev_switch("HYD_CORUN") != 0;
+}
 
 // per-level workspace: nsplit == 1 -> one dtype slice + lse; nsplit > 1 -> fp32 slices (prefix_ws_bytes)
 size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl) {
@@ -576,6 +608,10 @@ size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {
         PrefixPlan pl;
         if (plan_prefix(&pp, &pl, level_split_cap(p->n_levels))) return 0;
         total += level_ws_bytes(pp, pl);
+        if (i == 0 && corun_shapes_ok(p, pp, pl)) {  // either form may be chosen per call (phase): size for both
+            const size_t c = corun_ws_bytes((size_t)p->suffix.B * p->suffix.nq * p->suffix.Hq, p->suffix.D);
+            if (c > total) total = c;
+        }
     }
     return total;
 }
@@ -647,6 +683,47 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
     if (n_parts > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "%d partials (more than %d)", n_parts, kMaxCombine);
     if (need > 0 && (!p->workspace || p->workspace_bytes < need))
         return fail(HYD_ERR_WORKSPACE, "decode needs %zu workspace bytes, got %zu", need, p->workspace_bytes);
+
+    if (!small[0] && corun_wanted(p, pps[0], pls[0])) {
+        const size_t cneed = corun_ws_bytes(rows, sp.D);
+        if (!p->workspace || p->workspace_bytes < cneed)
+            return fail(HYD_ERR_WORKSPACE, "decode (co-run) needs %zu workspace bytes, got %zu", cneed, p->workspace_bytes);
+        char* w = static_cast<char*>(p->workspace);
+        const size_t ob = align_up(rows * sp.D * 4, 256), lb = align_up(rows * 4, 256);
+        float* po = reinterpret_cast<float*>(w);
+        float* pl_ = reinterpret_cast<float*>(w + ob);
+        float* so = reinterpret_cast<float*>(w + ob + lb);
+        float* sl = reinterpret_cast<float*>(w + 2 * ob + lb);
+        unsigned* queue = reinterpret_cast<unsigned*>(w + 2 * ob + 2 * lb);
+        PrefixArgs pa;
+        fill_prefix_args(&pps[0], pls[0], &pa);
+        pa.out = po;
+        pa.lse = pl_;
+        pa.out_f32 = 1;
+        pa.lse_layout = HYD_LSE_BQH;
+        SuffixArgs sa;
+        fill_suffix_args(&sp, &sa);
+        sa.out = so;
+        sa.lse = sl;
+        if (!corun_eligible(pa, sa, sp.D, false)) return fail(HYD_ERR_UNSUPPORTED, "co-run form chosen for a shape it does not cover");
+        const int np = dev_switch("HYD_CORUN_NP") ? dev_switch("HYD_CORUN_NP") : 2;
+        const int upi = dev_switch("HYD_CORUN_UPI") ? dev_switch("HYD_CORUN_UPI") : 8;
+        rc = launch_corun(pa, sa, sp.dtype, queue, kNumCU, np, upi, s);
+        if (rc) return fail(HYD_ERR_LAUNCH, "co-run kernel launch failed: hip error %d", rc);
+        CombineArgs c;
+        memset(&c, 0, sizeof(c));
+        c.outs[0] = po; c.lses[0] = pl_;
+        c.outs[1] = so; c.lses[1] = sl;
+        c.n = 2;
+        c.rows = (int64_t)rows;
+        c.D = sp.D;
+        c.dtype_in = HYD_F32;
+        c.dtype_out = sp.dtype;
+        c.out = sp.out;
+        c.lse_layout = HYD_LSE_BQH;
+        rc = launch_combine(c, s);
+        return rc ? fail(HYD_ERR_LAUNCH, "combine kernel launch failed: hip error %d", rc) : HYD_OK;
+    }
 
     hyd_partial parts[HYD_MAX_LEVELS];
     char* ws = static_cast<char*>(p->workspace);

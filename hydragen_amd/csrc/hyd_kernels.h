@@ -92,6 +92,13 @@ int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape);
 int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 int launch_combine(const CombineArgs& a, hipStream_t s);
+// co-run kernel (corun_attn.hip): prefix pass and suffix pass side by side in one launch; both write fp32 partials
+constexpr size_t kCorunQueueBytes = 1024;
+bool corun_eligible(const PrefixArgs& pa, const SuffixArgs& sa, int D, bool causal);
+int launch_corun(const PrefixArgs& pa, const SuffixArgs& sa, int dtype, unsigned* queue, int grid, int np_of8, int upi, hipStream_t s);
+bool gqa_stream_eligible(const SuffixArgs& a, int D);
+int launch_suffix_gqa_stream(const SuffixArgs& a, int dtype, unsigned* queue, int waves, int upi, hipStream_t s);
+int launch_suffix_stream_dev(const SuffixArgs& sa, int dtype, int grid, int upi, int nbuf, hipStream_t s);  // ablation builds only
 size_t allreduce_block_bytes(int world, size_t max_bytes);
 int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, void* out, int64_t count, int dtype,
                      int rank, int world, size_t max_bytes, hipStream_t s);

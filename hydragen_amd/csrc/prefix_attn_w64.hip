@@ -1,1052 +1,13 @@
-// Prefix pass: batched-query attention of all queries of a group against the group's single shared K/V, on the
-// gfx950 matrix cores.  Replaces flash-attn's _flash_attn_forward / _flash_attn_varlen_forward as called from
+// Prefix pass kernel + launcher: the unit body lives in prefix_unit_w64.h (it is also the prefix role of the co-run
+// kernel, corun_attn.hip).  Replaces flash-attn's _flash_attn_forward / _flash_attn_varlen_forward as called from
 // /root/reference/hydragen/flash.py:284-351 and hydragen/attention.py:270,313,344.
-//
-// Work decomposition (one wave per SIMD, the whole 512-entry register file per wave):
-//   workgroup = 256 threads = 4 waves; every wave owns 64 folded query rows (b_local, iq, gqa head) = two 32-row
-//   query blocks, so each K / V^T fragment read from LDS feeds TWO MFMAs (half the LDS, DMA and address traffic per
-//   flop of a 32-row wave) and the two blocks' softmax chains interleave in the MFMA shadow.
-//   KG = 2: 128 rows per workgroup, wave = (64-row half, key half of every 128-key tile); the two key halves keep
-//           independent (m, l, O) and are merged through LDS at the end.
-//   KG = 1: 256 rows per workgroup, every wave walks all keys (shapes with enough rows to fill the chip that way).
-//   S^T = K.Q^T and O^T += V^T.P^T with v_mfma_f32_32x32x16: computing the transposed products puts one query row per
-//   lane, so the softmax reductions are in-lane plus one v_permlane32_swap, and P^T is already the B operand.
-//
-// Pipeline (per wave, over 32-key blocks b): iteration i interleaves, instruction by instruction,
-//   MFMA stream: QK(i+1) and PV(i-1), alternating, each fragment used by both query blocks
-//   VALU stream: online softmax of block i for both query blocks (max3 tree, exp2, row sums, pack to 16-bit P^T)
-// with the order pinned by sched_barriers; the running maximum is only raised when a block exceeds it by more than
-// 2^kTau (the O rescale is a cold wave-uniform branch).  K and V live in LDS rings of four 32-key block slots filled by
-// LDS-DMA (buffer_load ... lds, zero fill past the end of the keys): iteration i issues K block i+4 and V block i+2
-// and its barrier only waits for the DMAs issued during iteration i-1.
-#include <type_traits>
-#include <utility>
-
-#include "hyd_kernels.h"
+#include "prefix_unit_w64.h"
 
 namespace hyd {
 
-namespace {
-
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_w;
-
-__device__ __forceinline__ u32x2 lds_tr16_w(unsigned lds_byte_addr) {
-    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_w)(uintptr_t)lds_byte_addr);
-    return __builtin_bit_cast(u32x2, t);
-}
-
-// One LDS-DMA instruction: 64 lanes x 16 B from global memory to LDS [lds_dst, lds_dst + 1 KiB) (lds_dst wave-uniform,
-// lane l lands at lds_dst + 16 l).  The source is a raw buffer resource plus a per-lane byte offset (+ a scalar byte
-// offset): lanes at or past num_records write zeros instead of faulting (tests/probes/bufdma_probe.hip), which is how
-// rows past the end of the keys, and whole blocks that do not exist, are handled without address arithmetic.
-// Issued from inline asm on purpose: hipcc then neither drains it (vmcnt(0)) in front of the LDS reads of the current
-// blocks nor counts it; the loop waits for it explicitly (dma_wait_w<N>) before its barrier.  M0 is not used by any
-// compiler-generated instruction of this kernel (gfx9 LDS instructions do not read it), so it is not saved.
-__device__ __forceinline__ void dma16w(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :
-                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ u32x4 make_rsrc_w(const char* base, unsigned bytes) {
-    const uint64_t b = (uint64_t)(uintptr_t)base;
-    u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void dma_wait_w() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-
-// MFMAs as inline asm with the O accumulators and the Q fragments in LITERAL accumulator registers that only these
-// statements touch: O block I = qb * NDB + db in a[16 I : 16 I + 15] (a[0:127]), Q fragment I = qb * NC + c in
-// a[128 + 4 I : 131 + 4 I] (a[128:191]); scores / P / K / V fragments stay in compiler-allocated VGPRs, where the VALU
-// works on them.  (Given 512 registers and MFMA builtins, or asm operands with register-class or even physical-register
-// constraints, hipcc routes scores and spills through AGPRs and migrates accumulators between the files across
-// iterations: 4-9 extra v_accvgpr_* per MFMA, scratch traffic and a vmcnt(0) inside the loop.)  The clobber lists make
-// the kernel descriptor allocate the registers; tests/test_build_quality.py asserts that no compiler-generated
-// instruction names an AGPR (the kernel has no spills, so hipcc has no use for them).
-// Hazards hipcc does not see (cdna_hip_programming.md 5.7): a score block is read by the VALU an iteration after the
-// MFMAs that wrote it were issued; P is consumed an iteration after the VALU packed it; every VALU access to an
-// accumulator (cold rescale, epilogue) is preceded by acc_drain(); v_accvgpr_write -> MFMA is padded inside the asm.
-template <int I>
-struct OAcc;
-template <int I>
-struct QFrag;
-template <>
-struct OAcc<0> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"v"(a), "v"(b) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[0:15], %0, %1, a[0:15]" ::"v"(a), "v"(b) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\ts_nop 1" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a0, %0\n\tv_accvgpr_read_b32 %0, a1\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a1, %0\n\tv_accvgpr_read_b32 %0, a2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a2, %0\n\tv_accvgpr_read_b32 %0, a3\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a3, %0\n\tv_accvgpr_read_b32 %0, a4\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a4, %0\n\tv_accvgpr_read_b32 %0, a5\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a5, %0\n\tv_accvgpr_read_b32 %0, a6\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a6, %0\n\tv_accvgpr_read_b32 %0, a7\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a7, %0\n\tv_accvgpr_read_b32 %0, a8\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a8, %0\n\tv_accvgpr_read_b32 %0, a9\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a9, %0\n\tv_accvgpr_read_b32 %0, a10\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a10, %0\n\tv_accvgpr_read_b32 %0, a11\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a11, %0\n\tv_accvgpr_read_b32 %0, a12\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a12, %0\n\tv_accvgpr_read_b32 %0, a13\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a13, %0\n\tv_accvgpr_read_b32 %0, a14\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a14, %0\n\tv_accvgpr_read_b32 %0, a15\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a15, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<1> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"v"(a), "v"(b) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[16:31], %0, %1, a[16:31]" ::"v"(a), "v"(b) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\ts_nop 1" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a16, %0\n\tv_accvgpr_read_b32 %0, a17\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a17, %0\n\tv_accvgpr_read_b32 %0, a18\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a18, %0\n\tv_accvgpr_read_b32 %0, a19\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a19, %0\n\tv_accvgpr_read_b32 %0, a20\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a20, %0\n\tv_accvgpr_read_b32 %0, a21\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a21, %0\n\tv_accvgpr_read_b32 %0, a22\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a22, %0\n\tv_accvgpr_read_b32 %0, a23\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a23, %0\n\tv_accvgpr_read_b32 %0, a24\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a24, %0\n\tv_accvgpr_read_b32 %0, a25\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a25, %0\n\tv_accvgpr_read_b32 %0, a26\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a26, %0\n\tv_accvgpr_read_b32 %0, a27\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a27, %0\n\tv_accvgpr_read_b32 %0, a28\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a28, %0\n\tv_accvgpr_read_b32 %0, a29\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a29, %0\n\tv_accvgpr_read_b32 %0, a30\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a30, %0\n\tv_accvgpr_read_b32 %0, a31\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a31, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<2> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"v"(a), "v"(b) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[32:47], %0, %1, a[32:47]" ::"v"(a), "v"(b) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\ts_nop 1" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a32, %0\n\tv_accvgpr_read_b32 %0, a33\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a33, %0\n\tv_accvgpr_read_b32 %0, a34\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a34, %0\n\tv_accvgpr_read_b32 %0, a35\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a35, %0\n\tv_accvgpr_read_b32 %0, a36\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a36, %0\n\tv_accvgpr_read_b32 %0, a37\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a37, %0\n\tv_accvgpr_read_b32 %0, a38\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a38, %0\n\tv_accvgpr_read_b32 %0, a39\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a39, %0\n\tv_accvgpr_read_b32 %0, a40\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a40, %0\n\tv_accvgpr_read_b32 %0, a41\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a41, %0\n\tv_accvgpr_read_b32 %0, a42\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a42, %0\n\tv_accvgpr_read_b32 %0, a43\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a43, %0\n\tv_accvgpr_read_b32 %0, a44\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a44, %0\n\tv_accvgpr_read_b32 %0, a45\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a45, %0\n\tv_accvgpr_read_b32 %0, a46\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a46, %0\n\tv_accvgpr_read_b32 %0, a47\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a47, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<3> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"v"(a), "v"(b) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[48:63], %0, %1, a[48:63]" ::"v"(a), "v"(b) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\ts_nop 1" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a48, %0\n\tv_accvgpr_read_b32 %0, a49\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a49, %0\n\tv_accvgpr_read_b32 %0, a50\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a50, %0\n\tv_accvgpr_read_b32 %0, a51\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a51, %0\n\tv_accvgpr_read_b32 %0, a52\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a52, %0\n\tv_accvgpr_read_b32 %0, a53\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a53, %0\n\tv_accvgpr_read_b32 %0, a54\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a54, %0\n\tv_accvgpr_read_b32 %0, a55\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a55, %0\n\tv_accvgpr_read_b32 %0, a56\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a56, %0\n\tv_accvgpr_read_b32 %0, a57\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a57, %0\n\tv_accvgpr_read_b32 %0, a58\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a58, %0\n\tv_accvgpr_read_b32 %0, a59\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a59, %0\n\tv_accvgpr_read_b32 %0, a60\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a60, %0\n\tv_accvgpr_read_b32 %0, a61\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a61, %0\n\tv_accvgpr_read_b32 %0, a62\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a62, %0\n\tv_accvgpr_read_b32 %0, a63\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a63, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\tv_accvgpr_read_b32 %8, a56\n\tv_accvgpr_read_b32 %9, a57\n\tv_accvgpr_read_b32 %10, a58\n\tv_accvgpr_read_b32 %11, a59\n\tv_accvgpr_read_b32 %12, a60\n\tv_accvgpr_read_b32 %13, a61\n\tv_accvgpr_read_b32 %14, a62\n\tv_accvgpr_read_b32 %15, a63" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<4> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" ::"v"(a), "v"(b) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[64:79], %0, %1, a[64:79]" ::"v"(a), "v"(b) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\ts_nop 1" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a64, %0\n\tv_accvgpr_read_b32 %0, a65\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a65, %0\n\tv_accvgpr_read_b32 %0, a66\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a66, %0\n\tv_accvgpr_read_b32 %0, a67\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a67, %0\n\tv_accvgpr_read_b32 %0, a68\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a68, %0\n\tv_accvgpr_read_b32 %0, a69\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a69, %0\n\tv_accvgpr_read_b32 %0, a70\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a70, %0\n\tv_accvgpr_read_b32 %0, a71\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a71, %0\n\tv_accvgpr_read_b32 %0, a72\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a72, %0\n\tv_accvgpr_read_b32 %0, a73\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a73, %0\n\tv_accvgpr_read_b32 %0, a74\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a74, %0\n\tv_accvgpr_read_b32 %0, a75\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a75, %0\n\tv_accvgpr_read_b32 %0, a76\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a76, %0\n\tv_accvgpr_read_b32 %0, a77\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a77, %0\n\tv_accvgpr_read_b32 %0, a78\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a78, %0\n\tv_accvgpr_read_b32 %0, a79\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a79, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\tv_accvgpr_read_b32 %8, a72\n\tv_accvgpr_read_b32 %9, a73\n\tv_accvgpr_read_b32 %10, a74\n\tv_accvgpr_read_b32 %11, a75\n\tv_accvgpr_read_b32 %12, a76\n\tv_accvgpr_read_b32 %13, a77\n\tv_accvgpr_read_b32 %14, a78\n\tv_accvgpr_read_b32 %15, a79" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<5> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" ::"v"(a), "v"(b) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[80:95], %0, %1, a[80:95]" ::"v"(a), "v"(b) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\ts_nop 1" ::: "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a80, %0\n\tv_accvgpr_read_b32 %0, a81\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a81, %0\n\tv_accvgpr_read_b32 %0, a82\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a82, %0\n\tv_accvgpr_read_b32 %0, a83\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a83, %0\n\tv_accvgpr_read_b32 %0, a84\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a84, %0\n\tv_accvgpr_read_b32 %0, a85\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a85, %0\n\tv_accvgpr_read_b32 %0, a86\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a86, %0\n\tv_accvgpr_read_b32 %0, a87\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a87, %0\n\tv_accvgpr_read_b32 %0, a88\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a88, %0\n\tv_accvgpr_read_b32 %0, a89\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a89, %0\n\tv_accvgpr_read_b32 %0, a90\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a90, %0\n\tv_accvgpr_read_b32 %0, a91\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a91, %0\n\tv_accvgpr_read_b32 %0, a92\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a92, %0\n\tv_accvgpr_read_b32 %0, a93\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a93, %0\n\tv_accvgpr_read_b32 %0, a94\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a94, %0\n\tv_accvgpr_read_b32 %0, a95\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a95, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\tv_accvgpr_read_b32 %8, a88\n\tv_accvgpr_read_b32 %9, a89\n\tv_accvgpr_read_b32 %10, a90\n\tv_accvgpr_read_b32 %11, a91\n\tv_accvgpr_read_b32 %12, a92\n\tv_accvgpr_read_b32 %13, a93\n\tv_accvgpr_read_b32 %14, a94\n\tv_accvgpr_read_b32 %15, a95" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<6> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" ::"v"(a), "v"(b) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[96:111], %0, %1, a[96:111]" ::"v"(a), "v"(b) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\ts_nop 1" ::: "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a96, %0\n\tv_accvgpr_read_b32 %0, a97\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a97, %0\n\tv_accvgpr_read_b32 %0, a98\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a98, %0\n\tv_accvgpr_read_b32 %0, a99\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a99, %0\n\tv_accvgpr_read_b32 %0, a100\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a100, %0\n\tv_accvgpr_read_b32 %0, a101\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a101, %0\n\tv_accvgpr_read_b32 %0, a102\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a102, %0\n\tv_accvgpr_read_b32 %0, a103\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a103, %0\n\tv_accvgpr_read_b32 %0, a104\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a104, %0\n\tv_accvgpr_read_b32 %0, a105\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a105, %0\n\tv_accvgpr_read_b32 %0, a106\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a106, %0\n\tv_accvgpr_read_b32 %0, a107\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a107, %0\n\tv_accvgpr_read_b32 %0, a108\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a108, %0\n\tv_accvgpr_read_b32 %0, a109\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a109, %0\n\tv_accvgpr_read_b32 %0, a110\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a110, %0\n\tv_accvgpr_read_b32 %0, a111\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a111, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\tv_accvgpr_read_b32 %8, a104\n\tv_accvgpr_read_b32 %9, a105\n\tv_accvgpr_read_b32 %10, a106\n\tv_accvgpr_read_b32 %11, a107\n\tv_accvgpr_read_b32 %12, a108\n\tv_accvgpr_read_b32 %13, a109\n\tv_accvgpr_read_b32 %14, a110\n\tv_accvgpr_read_b32 %15, a111" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<7> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" ::"v"(a), "v"(b) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[112:127], %0, %1, a[112:127]" ::"v"(a), "v"(b) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0\n\ts_nop 1" ::: "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a112, %0\n\tv_accvgpr_read_b32 %0, a113\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a113, %0\n\tv_accvgpr_read_b32 %0, a114\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a114, %0\n\tv_accvgpr_read_b32 %0, a115\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a115, %0\n\tv_accvgpr_read_b32 %0, a116\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a116, %0\n\tv_accvgpr_read_b32 %0, a117\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a117, %0\n\tv_accvgpr_read_b32 %0, a118\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a118, %0\n\tv_accvgpr_read_b32 %0, a119\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a119, %0\n\tv_accvgpr_read_b32 %0, a120\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a120, %0\n\tv_accvgpr_read_b32 %0, a121\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a121, %0\n\tv_accvgpr_read_b32 %0, a122\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a122, %0\n\tv_accvgpr_read_b32 %0, a123\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a123, %0\n\tv_accvgpr_read_b32 %0, a124\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a124, %0\n\tv_accvgpr_read_b32 %0, a125\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a125, %0\n\tv_accvgpr_read_b32 %0, a126\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a126, %0\n\tv_accvgpr_read_b32 %0, a127\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a127, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a120\n\tv_accvgpr_read_b32 %9, a121\n\tv_accvgpr_read_b32 %10, a122\n\tv_accvgpr_read_b32 %11, a123\n\tv_accvgpr_read_b32 %12, a124\n\tv_accvgpr_read_b32 %13, a125\n\tv_accvgpr_read_b32 %14, a126\n\tv_accvgpr_read_b32 %15, a127" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct QFrag<0> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[128:131], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a128", "a129", "a130", "a131");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[128:131], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[128:131], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[128:131], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[128:131], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<1> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[132:135], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a132", "a133", "a134", "a135");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[132:135], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[132:135], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[132:135], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[132:135], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<2> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[136:139], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a136", "a137", "a138", "a139");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[136:139], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[136:139], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[136:139], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[136:139], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<3> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[140:143], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a140", "a141", "a142", "a143");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[140:143], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[140:143], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[140:143], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[140:143], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<4> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[144:147], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a144", "a145", "a146", "a147");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[144:147], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[144:147], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[144:147], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[144:147], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<5> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[148:151], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a148", "a149", "a150", "a151");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[148:151], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[148:151], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[148:151], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[148:151], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<6> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[152:155], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a152", "a153", "a154", "a155");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[152:155], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[152:155], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[152:155], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[152:155], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<7> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[156:159], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a156", "a157", "a158", "a159");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[156:159], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[156:159], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[156:159], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[156:159], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<8> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[160:163], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a160", "a161", "a162", "a163");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[160:163], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[160:163], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[160:163], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[160:163], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<9> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[164:167], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a164", "a165", "a166", "a167");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[164:167], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[164:167], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[164:167], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[164:167], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<10> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[168:171], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a168", "a169", "a170", "a171");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[168:171], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[168:171], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[168:171], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[168:171], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<11> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[172:175], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a172", "a173", "a174", "a175");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[172:175], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[172:175], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[172:175], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[172:175], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<12> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[176:179], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a176", "a177", "a178", "a179");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[176:179], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[176:179], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[176:179], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[176:179], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<13> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[180:183], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a180", "a181", "a182", "a183");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[180:183], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[180:183], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[180:183], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[180:183], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<14> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[184:187], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a184", "a185", "a186", "a187");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[184:187], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[184:187], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[184:187], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[184:187], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<15> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[188:191], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a188", "a189", "a190", "a191");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[188:191], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[188:191], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[188:191], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[188:191], %0" : "+v"(s) : "v"(a));
-    }
-};
-// every MFMA issued so far has written its result (8-pass XDL: 18 wait states cover any reader)
-__device__ __forceinline__ void acc_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
-// Element phase of one query block's softmax: 56 operations on the 8 element pairs, software-pipelined.  Step st handles
-// {fma, fma, exp2, exp2} of pair st (st < 8) interleaved with {row-sum add, add, pack} of pair st - LAG (st >= LAG).
-// Positions: 0 fma a, 1 fma b, 2 add0 old, 3 exp a, 4 add1 old, 5 exp b, 6 pack old.  Returns step * 8 + position.
-template <int LAG>
-constexpr int elem_op_code(int k) {
-    for (int st = 0; st < 8 + LAG; ++st) {
-        const bool cur = st < 8, old = st >= LAG;
-        const int n = (cur ? 4 : 0) + (old ? 3 : 0);
-        if (k < n) {
-            const int co[4] = {0, 1, 3, 5}, oo[3] = {2, 4, 6};
-            return st * 8 + ((cur && old) ? k : cur ? co[k] : oo[k]);
-        }
-        k -= n;
-    }
-    return -1;
-}
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
-
-}  // namespace
-
-// ABL: development-only timing ablations (bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
-// bit4 no barrier in the loop, bit5 no exp2, bit6 no element phase, bit7 no row sums / pack); only ABL = 0 ships.
-template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
-__device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
-    using TR = Traits<T>;
-    constexpr int QB = 2;                // 32-row query blocks per wave
-    constexpr int RB = D * 2;            // bytes per K/V row
-    constexpr int NC = D / 16;           // k-chunks of the QK^T contraction
-    constexpr int NDB = D / 32;          // 32-wide d blocks of O^T
-    constexpr int RWG = KG == 2 ? 128 : 256;                 // query rows per workgroup
-    constexpr int BROWS = KG == 2 ? 64 : 32;                  // K (or V) rows staged per iteration
-    constexpr int NLB = BROWS * RB / 1024 / 4;                // DMA instructions per wave per tensor per iteration
-    constexpr int RPI = 1024 / RB;                            // rows per DMA instruction
-    static_assert(NLB >= 1, "every wave issues at least one DMA instruction per tensor and iteration");
-    constexpr int RING_BYTES = (KG == 2 ? 512 : 256) * RB;
-    float* mlbuf = reinterpret_cast<float*>(smem + RING_BYTES);  // [4 waves][QB][2][64] (KG = 2 merge)
-
-    unsigned tst[6] = {0, 0, 0, 0, 0, 0};  // ABL bit 11: cycle stamps of workgroup 0 (development builds only)
-    auto stampk = [&](int k) __attribute__((always_inline)) {
-        if constexpr ((ABL & 2048) != 0) {
-            uint64_t t;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-            tst[k] = (unsigned)t;
-        }
-    };
-    stampk(0);
-    // Opaque per unit: a persistent workgroup calls this in a loop, and everything derived from the lane index is
-    // loop-invariant there -- hoisted out of the unit loop it would stay live across the whole pipeline and push the
-    // allocation past 256 VGPRs (hipcc then parks values in AGPRs, which the asm statements own).
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = KG == 2 ? wave >> 1 : 0;   // key half of every 128-key tile this wave computes on
-    const int rw = KG == 2 ? wave & 1 : wave; // 64-row sub-block
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    // ---- which (group, kv head, split, row block) ------------------------------------------
-    const int lin = xcd_remap(vblock, vgrid);
-    const int rb = lin % a.row_blocks;
-    int t_ = lin / a.row_blocks;
-    const int sp = t_ % a.nsplit;
-    t_ /= a.nsplit;
-    const int hk = t_ % a.Hkv;
-    const int gi = t_ / a.Hkv;
-
-    int q_tok0, nqtok, nq_eff;
-    if (a.cu_q) {
-        q_tok0 = a.cu_q[gi];
-        nqtok = a.cu_q[gi + 1] - q_tok0;
-        nq_eff = nqtok;
-    } else {
-        q_tok0 = gi * a.per * a.nq;
-        nqtok = a.per * a.nq;
-        nq_eff = a.nq;
-    }
-    const int Mrows = nqtok * a.g;
-    if (rb * RWG >= Mrows) return;  // block-uniform
-
-    const uint16_t* k16 = static_cast<const uint16_t*>(a.k);
-    const uint16_t* v16 = static_cast<const uint16_t*>(a.v);
-    int L;
-    if (a.cu_k) {
-        const int t0 = a.cu_k[gi];
-        L = a.cu_k[gi + 1] - t0;
-        k16 += (int64_t)t0 * a.k_ts;
-        v16 += (int64_t)t0 * a.v_ts;
-    } else {
-        L = a.kv_len;
-        k16 += (int64_t)gi * a.k_gs;
-        v16 += (int64_t)gi * a.v_gs;
-    }
-    k16 += (int64_t)hk * a.k_hs;
-    v16 += (int64_t)hk * a.v_hs;
-
-    const int kbeg = sp * a.split_len;
-    int kend = min(L, kbeg + a.split_len);
-    if (CAUSAL && a.per == 1) {
-        // rows of this block only see keys <= iq_max + L - nq
-        const int rmax = min(Mrows, rb * RWG + RWG) - 1;
-        kend = min(kend, rmax / a.g + L - nq_eff + 1);
-    }
-    const int nkeys = kend > kbeg ? kend - kbeg : 0;
-    // 32-key blocks per wave: its half of every 128-key tile (KG = 2) or all keys (KG = 1); even, the loop runs in pairs
-    const int NB = KG == 2 ? 2 * ((nkeys + 127) >> 7) : 2 * ((nkeys + 63) >> 6);
-
-    // ---- this lane's query rows (one per query block), fetched straight into AGPRs ---------------------------------
-    // (B operands of the QK^T MFMAs for the whole kernel.)  Rows past the end are clamped to the last valid row: every
-    // lane computes an independent query row, and an invalid lane never stores.
-    bool rvalid[QB];
-    int rtok[QB], hq[QB], row_lim[QB];
-    int64_t row_off[QB];
-    const uint16_t* qrow_p[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int r = rb * RWG + rw * 64 + qb * 32 + l31;
-        rvalid[qb] = r < Mrows;
-        const int rc = min(r, Mrows - 1);
-        rtok[qb] = rc / a.g;  // query token inside the group
-        hq[qb] = hk * a.g + rc % a.g;
-        row_off[qb] = ((int64_t)(q_tok0 + rtok[qb]) * a.Hq + hq[qb]) * D;
-        row_lim[qb] = CAUSAL ? (rtok[qb] % nq_eff) + L - nq_eff : 0x3fffffff;  // last visible key
-        qrow_p[qb] = static_cast<const uint16_t*>(a.q) + row_off[qb] + 8 * hi;
-    }
-    static_for<QB * NC>([&](auto I_) {
-        constexpr int I = decltype(I_)::value;
-        QFrag<I>::template load<32 * (I % NC)>(qrow_p[I / NC]);
-    });
-
-    // ---- LDS map (bytes) ------------------------------------------------------------------------------------
-    // KG = 2: KA[2 tiles x 64 rows] | KB[2 tiles x 64 rows] | V[2 tiles x 128 rows] | mlbuf.  KA: rows 0..63 of a
-    // 128-key K tile (kg = 0 waves), KB: rows 64..127 (kg = 1 waves).  Ring slot s (block b, s = b & 3): tile buffer
-    // s >> 1, rows [(s & 1) * 32, +32) of each 64-row half.
-    // KG = 1: K[4 slots of 32 rows] | V[4 slots of 32 rows] | mlbuf.
-    constexpr int KH_BYTES = 64 * RB;
-    constexpr int V_BYTES = KG == 2 ? 128 * RB : 64 * RB;  // two ring slots of V
-    constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = KG == 2 ? 4 * KH_BYTES : 2 * KH_BYTES;
-    typedef const __attribute__((address_space(3))) char* lptr_c;
-    auto slot_k = [](int s) { return KG == 2 ? (s >> 1) * KH_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
-    auto slot_v = [](int s) { return KG == 2 ? (s >> 1) * V_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
-
-    // ---- per-lane LDS byte addresses of the MFMA fragments (ring slot 0) -------------------------------
-    const int ksw = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
-    const int kx = hi ^ ksw;
-    unsigned kaddr[NC];  // K fragment c of row l31 in slot 0 of this wave's key half (KA or KB)
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        kaddr[c] = (unsigned)(uintptr_t)(lptr_c)(smem + (kg ? KB_OFF : KA_OFF) + l31 * RB + (((2 * c) ^ kx) << 4));
-    const int i16 = lane & 15, g16 = lane >> 4;
-    const int vsw = D == 128 ? (i16 >> 2) : ((i16 >> 3) & 1);
-    unsigned vaddr[NDB];  // V^T fragment address in slot 0 for key slot 0 of this wave's half
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        vaddr[db] = (unsigned)(uintptr_t)(lptr_c)(smem + V_OFF + (kg * 64 + 4 * hi + (i16 >> 2)) * RB +
-                                                  ((db ^ vsw) << 6) + 32 * (g16 & 1) + 8 * (i16 & 3));
-
-    // ---- staging: global -> LDS DMA, BROWS rows per tensor and iteration, NLB instructions per wave ----------
-    // The LDS image of a wave instruction is lane-linear (base + lane * 16), so the XOR swizzles are applied to the
-    // per-lane SOURCE chunk (involutions inside a row).  Instruction q = wave * NLB + i covers rows
-    // rr = q * RPI + [0, RPI) of the staged rows: half h = rr >> 5 (KG = 2), row r32 = rr & 31.
-    const int drow = (lane * 16) / RB;        // row inside the instruction
-    const int dcp = ((lane * 16) % RB) >> 4;  // 16-byte slot inside the row (LDS side)
-    unsigned koffb[NLB], voffb[NLB];  // per-lane source byte offsets relative to the block's first row
-    unsigned kdst[NLB], vdst[NLB];    // wave-uniform LDS byte address of the instruction in ring slot 0
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_c)smem;
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const int q = wave * NLB + i;
-        const int rr = q * RPI + drow, h = KG == 2 ? rr >> 5 : 0, r32 = rr & 31;
-        const int kch = D == 128 ? (dcp ^ (r32 & 15)) : (dcp ^ ((r32 >> 1) & 7));
-        const int vs_ = D == 128 ? (r32 & 3) : ((r32 >> 1) & 1);
-        const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
-        const int drr = h * 64 + r32;  // row inside the 128-key tile (KG = 2) / the block (KG = 1)
-        koffb[i] = (unsigned)(((int64_t)drr * a.k_ts + kch * 8) * 2);
-        voffb[i] = (unsigned)(((int64_t)drr * a.v_ts + vch * 8) * 2);
-        const int qh = KG == 2 ? (q * RPI) >> 5 : 0, qr = (q * RPI) & 31;  // wave-uniform
-        kdst[i] = __builtin_amdgcn_readfirstlane(lds0 + (qh ? KB_OFF : KA_OFF) + qr * RB);
-        vdst[i] = __builtin_amdgcn_readfirstlane(lds0 + V_OFF + (qh * 64 + qr) * RB);
-    }
-    // One buffer resource per tensor for the whole pass: rows [kbeg, kend) of this (group, head); a block's first row
-    // goes into the scalar offset.  Blocks / rows at or past the end read as zeros.
-    const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
-    const u32x4 krs = make_rsrc_w(reinterpret_cast<const char*>(k16) + (int64_t)kbeg * a.k_ts * 2,
-                                  nkeys > 0 ? (unsigned)(nkeys - 1) * k_ts2 + RB : 0u);
-    const u32x4 vrs = make_rsrc_w(reinterpret_cast<const char*>(v16) + (int64_t)kbeg * a.v_ts * 2,
-                                  nkeys > 0 ? (unsigned)(nkeys - 1) * v_ts2 + RB : 0u);
-    auto row0_of = [&](int b) -> int { return KG == 2 ? (b >> 1) * 128 + (b & 1) * 32 : b * 32; };
-    // a block whose first row is past the keys gets an offset past num_records: the whole instruction zero-fills
-    auto soff_of = [&](int b, unsigned ts2) -> unsigned {
-        const int r0 = row0_of(b);
-        return __builtin_amdgcn_readfirstlane(r0 < nkeys + 128 ? (unsigned)r0 * ts2 : 0x7fff0000u);
-    };
-    auto dma_block = [&](int b, bool isv) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            if (isv) dma16w(vrs, voffb[i], soff_of(b, v_ts2), vdst[i] + slot_v(b & 3));
-            else dma16w(krs, koffb[i], soff_of(b, k_ts2), kdst[i] + slot_k(b & 3));
-        }
-    };
-
-    static_for<QB * NDB>([&](auto I_) { OAcc<decltype(I_)::value>::zero(); });
-    // Online-softmax state per query block, in RAW score units (before the scale): the reference maximum m_raw (equal in
-    // the two lanes of a row), nms = -sc * m_raw and the threshold thr = m_raw + kTau / sc above which a block's lane
-    // maximum forces a new reference.  kMinit is a finite "minus infinity": exp2(sc * (m_old - m_new)) never sees inf - inf.
-    constexpr float kMinit = -1.0e30f;
-    float m_raw[QB], nms[QB], thr[QB], l_run[QB];
-    f32x16 S0[QB], S1[QB];
-    u32x4 P0[QB][2], P1[QB][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m_raw[qb] = kMinit;
-        thr[qb] = kMinit;
-        nms[qb] = 0.f;
-        l_run[qb] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S0[qb][i] = S1[qb][i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) P0[qb][i] = P1[qb][i] = u32x4{0u, 0u, 0u, 0u};
-    }
-    const float sc = a.scale_log2e;
-    constexpr float kTau = 8.0f;
-    const float tau_raw = kTau / sc;
-
-    // ---- one pipeline iteration i: QK(i+1) | SM(i) | PV(i-1) -------------------------------------------
-    // KOFF / VOFF: compile-time ring-slot byte offsets of K block i+1 and V block i-1;
-    // NKOFF / NVOFF: the same for iteration i+1, whose first fragments are prefetched in the tail of this one.
-    // FL: bit0 QK, bit1 SM, bit2 PV, bit3 the softmax may need masking, bit4 / bit5: iteration i+1 has QK / PV.
-    // DM: 1 = issue the DMAs of K block i+4 and V block i+2 into ring slots kslot / vslot, spread between the MFMAs.
-    // bvalid: block i exists.  Sw: scores written by QK; Sr: scores consumed by the softmax, which writes Pw; PV reads Pr.
-    // kw: first key of block i for this wave (masking).
-    constexpr int PDK = 3, PDV = 2;  // LDS prefetch distance (in fragment reads of the own stream)
-    u32x4 kfr[PDK];
-    u32x2 vfr[PDV][2];
-#pragma unroll
-    for (int c = 0; c < PDK; ++c) kfr[c] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int p = 0; p < PDV; ++p) vfr[p][0] = vfr[p][1] = u32x2{0u, 0u};
-    auto ldk_at = [&](int c, int off) -> u32x4 {
-        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(kaddr[c] + off));
-    };
-    auto ldv_at = [&](int p, int h, int off) -> u32x2 {  // PV MFMA p = ks * NDB + db; h = 8-key half of the slot
-        return lds_tr16_w(vaddr[p % NDB] + off + (16 * (p / NDB) + 8 * h) * RB);
-    };
-    auto iter = [&](auto KOFF_C, auto VOFF_C, auto NKOFF_C, auto NVOFF_C, auto FL_C, auto DM_C, f32x16(&Sw)[QB],
-                    f32x16(&Sr)[QB], u32x4(&Pw)[QB][2], u32x4(&Pr)[QB][2], int kw, bool bvalid, unsigned ksoff,
-                    unsigned vsoff, int kslot, int vslot) __attribute__((always_inline)) {
-        constexpr int KOFF = decltype(KOFF_C)::value;
-        constexpr int VOFF = decltype(VOFF_C)::value;
-        constexpr int NKOFF = decltype(NKOFF_C)::value;
-        constexpr int NVOFF = decltype(NVOFF_C)::value;
-        constexpr int FL = decltype(FL_C)::value;
-        constexpr int DM = decltype(DM_C)::value;
-        constexpr bool QK = FL & 1, SM = FL & 2, PV = FL & 4, MASK = (FL & 8) || CAUSAL;
-        constexpr bool NQK = FL & 16, NPVF = FL & 32;
-        constexpr int NPV = 2 * NDB;        // PV fragment steps (2 key slots x NDB d blocks)
-        constexpr int NSLOT = NC + NPV;     // MFMA slots (QB MFMAs each); QK and PV alternate
-        constexpr int NG = 16;              // VALU groups of one query block's softmax
-        auto ldk = [&](int c) -> u32x4 { return ldk_at(c, KOFF); };
-        auto ldv = [&](int p, int h) -> u32x2 { return ldv_at(p, h, VOFF); };
-        // softmax state of this iteration
-        float t0[QB], t1[QB], t2[QB], t3[QB], t4[QB], tmax[QB], alpha[QB], su0[QB], su1[QB];
-        bool upf[QB];
-        bool pend = false;  // a new reference maximum was adopted in this iteration: O and l are rescaled at its end
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            t0[qb] = t1[qb] = t2[qb] = t3[qb] = t4[qb] = tmax[qb] = su0[qb] = su1[qb] = 0.f;
-            alpha[qb] = 1.f;
-            upf[qb] = false;
-        }
-        if constexpr (SM && MASK) {
-            bool need_mask = !bvalid || (kw + 32 > kend);
-            if (CAUSAL) need_mask = need_mask || __builtin_amdgcn_ballot_w64(min(row_lim[0], row_lim[1]) < kw + 31) != 0ull;
-            if (need_mask) {
-                asm volatile("" ::: "memory");  // keep this a (cold) branch
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    int lim = kend - 1;
-                    if (CAUSAL) lim = min(lim, row_lim[qb]);
-                    const int lr = bvalid ? lim - kw - 4 * hi : -1;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (8 * (i >> 2) + (i & 3) > lr) Sr[qb][i] = -INFINITY;
-                }
-            }
-        }
-        // Softmax of one query block as NG = 16 groups of 4-5 VALU instructions, one group behind each of the block's 16
-        // MFMAs (an MFMA's shadow holds ~5 issue slots; every instruction beyond it costs its full issue time).
-        //   g0-g1 lane-local maximum of the 16 raw scores (max3 tree) and ONE compare against the threshold.  Only when
-        //         some lane exceeds it (cold, wave-uniform) are the half-wave exchange, the new reference, alpha and the
-        //         O / l rescale executed -- the hot path never touches m, nms or alpha.
-        //   g2-g15: 56 element operations, software-pipelined over the 8 element pairs: step s = {fma, fma, exp2, exp2} of
-        //         pair s interleaved with {row-sum add, add, pack} of pair s - LAG (scalar f32 ops on purpose: packed f32
-        //         VALU beside MFMAs costs more than the two scalar instructions it replaces).
-        constexpr int LAG = 2;
-        auto elem_op = [&](auto K_, int qb) __attribute__((always_inline)) {
-            f32x16& S = Sr[qb];
-            constexpr int code = elem_op_code<LAG>(decltype(K_)::value);
-            constexpr int step = code >> 3, pos = code & 7;
-            constexpr int ea = 2 * step, ep = 2 * (step - LAG);  // elements of this step's pair / of the old pair
-            if constexpr ((ABL & 64) || ((ABL & 32) && (pos == 3 || pos == 5)) || ((ABL & 128) && (pos == 2 || pos == 4 || pos == 6)))
-                return;
-            else if constexpr (pos == 0) { S[ea] = __builtin_fmaf(S[ea], sc, nms[qb]); asm volatile("" : "+v"(S[ea])); }
-            else if constexpr (pos == 1) { S[ea + 1] = __builtin_fmaf(S[ea + 1], sc, nms[qb]); asm volatile("" : "+v"(S[ea + 1])); }
-            else if constexpr (pos == 3) { S[ea] = fast_exp2(S[ea]); asm volatile("" : "+v"(S[ea])); }
-            else if constexpr (pos == 5) { S[ea + 1] = fast_exp2(S[ea + 1]); asm volatile("" : "+v"(S[ea + 1])); }
-            else if constexpr (pos == 2) { su0[qb] += S[ep]; asm volatile("" : "+v"(su0[qb])); }
-            else if constexpr (pos == 4) { su1[qb] += S[ep + 1]; asm volatile("" : "+v"(su1[qb])); }
-            else {  // element pair kk = ep / 2 -> P^T slot (kk >> 2), word (kk & 3)
-                constexpr int kk = ep / 2;
-                Pw[qb][kk >> 2][kk & 3] = TR::pack2(S[ep], S[ep + 1]);
-                asm volatile("" ::"v"(Pw[qb][kk >> 2][kk & 3]));
-            }
-        };
-        auto valu_group = [&](auto G_, int qb) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value;
-            if constexpr (SM && !(ABL & 4)) {
-                f32x16& S = Sr[qb];
-                if constexpr (g == 0) {
-                    t0[qb] = fmaxf(fmaxf(S[0], S[1]), S[2]);
-                    t1[qb] = fmaxf(fmaxf(S[3], S[4]), S[5]);
-                    t2[qb] = fmaxf(fmaxf(S[6], S[7]), S[8]);
-                    t3[qb] = fmaxf(fmaxf(S[9], S[10]), S[11]);
-                    t4[qb] = fmaxf(fmaxf(S[12], S[13]), S[14]);
-                    asm volatile("" ::"v"(t0[qb]), "v"(t1[qb]), "v"(t2[qb]), "v"(t3[qb]), "v"(t4[qb]));
-                } else if constexpr (g == 1) {
-                    t0[qb] = fmaxf(fmaxf(t0[qb], t1[qb]), S[15]);
-                    t2[qb] = fmaxf(fmaxf(t2[qb], t3[qb]), t4[qb]);
-                    tmax[qb] = fmaxf(t0[qb], t2[qb]);
-                    upf[qb] = tmax[qb] > thr[qb];
-                    asm volatile("" ::"v"(tmax[qb]));
-                } else {
-                    constexpr int k0 = ((g - 2) * 56) / 14, k1 = ((g - 1) * 56) / 14;
-                    static_for<k1 - k0>([&](auto K_) __attribute__((always_inline)) {
-                        elem_op(std::integral_constant<int, k0 + decltype(K_)::value>{}, qb);
-                    });
-                }
-            }
-        };
-        constexpr bool BF = std::is_same<T, BF16>::value;
-        // An in-order wave that issues two MFMAs back to back sits at the second one until the matrix pipe frees (32
-        // cycles) and nothing behind it issues: only ONE MFMA's shadow per pair would carry VALU work (measured: the
-        // softmax then adds its full issue time to the loop).  So every MFMA is followed by its own share of the other
-        // streams: MFMA(qb 0) | softmax group of qb 0 | MFMA(qb 1) | softmax group of qb 1 | LDS prefetch, DMA.
-        static_for<NSLOT>([&](auto J_) __attribute__((always_inline)) {
-            constexpr int j = decltype(J_)::value;
-            // MFMAs of this slot: even -> QK chunk j/2, odd -> PV step j/2; one fragment, QB MFMAs
-            constexpr int idx = j >> 1;
-            constexpr bool isqk = (j & 1) == 0;
-            u32x4 vf = {0u, 0u, 0u, 0u};
-            if constexpr (!isqk && PV) vf = u32x4{vfr[idx % PDV][0][0], vfr[idx % PDV][0][1], vfr[idx % PDV][1][0], vfr[idx % PDV][1][1]};
-            static_for<QB>([&](auto B_) __attribute__((always_inline)) {
-                constexpr int qb = decltype(B_)::value;
-                if constexpr (isqk) {
-                    if constexpr (QK) QFrag<qb * NC + idx>::template qk<BF, idx == 0>(Sw[qb], kfr[idx % PDK]);
-                } else {
-                    if constexpr (PV) OAcc<qb * NDB + idx % NDB>::template pv<BF>(vf, Pr[qb][idx / NDB]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                constexpr int g0 = (j * NG) / NSLOT, g1 = ((j + 1) * NG) / NSLOT;
-                static_for<g1 - g0>([&](auto G_) __attribute__((always_inline)) {
-                    valu_group(std::integral_constant<int, g0 + decltype(G_)::value>{}, qb);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (SM && !(ABL & 4) && (j * NG) / NSLOT <= 1 && 1 < ((j + 1) * NG) / NSLOT) {
-                // both query blocks know their lane maxima: adopt a new reference maximum?  (cold, wave-uniform)
-                if (__builtin_amdgcn_ballot_w64(upf[0] || upf[1]) != 0ull) {
-                    asm volatile("" ::: "memory");  // keep this a branch
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        const float tm = pair_max(tmax[qb]);  // the row's maximum: both lanes of a row decide alike
-                        const float newm = tm > thr[qb] ? tm : m_raw[qb];
-                        alpha[qb] = fast_exp2((m_raw[qb] - newm) * sc);
-                        m_raw[qb] = newm;
-                        nms[qb] = -newm * sc;
-                        thr[qb] = newm + tau_raw;
-                    }
-                    pend = true;
-                }
-            }
-            if constexpr (isqk) {
-                if constexpr (QK) {
-                    if (idx + PDK < NC && !(ABL & 8)) kfr[idx % PDK] = ldk(idx + PDK);
-                }
-            } else {
-                if constexpr (PV) {
-                    if (idx + PDV < NPV && !(ABL & 8)) { vfr[idx % PDV][0] = ldv(idx + PDV, 0); vfr[idx % PDV][1] = ldv(idx + PDV, 1); }
-                }
-            }
-            if constexpr (DM == 1 && !(ABL & 1)) {
-                // 2 * NLB DMA instructions spread over the iteration (odd slots first)
-                constexpr int EVERY = NSLOT / (2 * NLB) > 1 ? 2 : 1;
-                if constexpr ((j % EVERY) == EVERY - 1 && j / EVERY < 2 * NLB) {
-                    constexpr int i = j / EVERY;
-                    if constexpr (i < NLB) dma16w(krs, koffb[i], ksoff, kdst[i] + kslot);
-                    else dma16w(vrs, voffb[i - NLB], vsoff, vdst[i - NLB] + vslot);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // first fragments of iteration i+1 (its blocks are already visible, see the header)
-        if constexpr (NQK) {
-#pragma unroll
-            for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, NKOFF);
-        }
-        if constexpr (NPVF) {
-#pragma unroll
-            for (int p = 0; p < PDV; ++p) { vfr[p][0] = ldv_at(p, 0, NVOFF); vfr[p][1] = ldv_at(p, 1, NVOFF); }
-        }
-        if constexpr (SM && !(ABL & 4)) {
-            if (pend) {  // cold: at most a handful of times per row block.  Every PV(i-1) MFMA has been issued: all of O
-                         // and l is still at the old reference and is rescaled exactly once; P(i) is at the new one.
-                acc_drain();
-                static_for<QB * NDB>([&](auto I_) { constexpr int I = decltype(I_)::value; OAcc<I>::scale(alpha[I / NDB]); });
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) l_run[qb] *= alpha[qb];
-            }
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) l_run[qb] += su0[qb] + su1[qb];
-        }
-    };
-
-    // ---- pipeline over 32-key blocks ---------------------------------------------------------------------
-    using std::integral_constant;
-#define HYD_IC(x) integral_constant<int, (x)>{}
-    const int kwave = kbeg + kg * 64;  // first key of this wave's half of tile 0
-    // Iterations i = -1 .. NB; the pipeline's fill (i = -1: QK(0) only; i = 0: QK(1) + softmax(0)) and drain
-    // (i = NB-1: softmax + PV, no QK; i = NB: PV(NB-1) only) run their own, shorter instantiations of the iteration.
-    // Cold start: only what the first iteration needs is waited for (Q, K blocks 0 and 1); K block 2 and V block 0 are
-    // issued behind that wait and land during iterations -1 / 0.
-    if (NB > 0) {
-        dma_block(0, false);
-        dma_block(1, false);
-    }
-    // Wait for the Q fragments (asm loads: hipcc does not count them) and the first two K blocks; every consumer is
-    // a volatile asm statement behind this one.
-    stampk(1);
-    dma_wait_w<0>();
-    if (NB > 0) {
-        dma_block(2, false);  // covered by the counted wait that ends iteration -1
-        dma_block(0, true);
-    }
-    __syncthreads();
-    stampk(2);
-    if (NB > 0) {
-#pragma unroll
-        for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, slot_k(0));
-        // ii = i0 + R = -1 + R (mod 4), so every ring slot is a compile-time constant:
-        //   reads  K block ii+1 -> slot R, V block ii-1 -> slot (R+2)&3;  next iteration: (R+1)&3, (R+3)&3
-        //   writes K block ii+4 -> slot (R+3)&3, V block ii+2 -> slot (R+1)&3.      ii odd <=> R even.
-        // FL: 1 QK | 2 softmax | 4 PV | 8 masking possible | 16 / 32: the next iteration has QK / PV (fragment prefetch)
-        constexpr int FL_FULL = 7 + 8 + 16 + 32, FL_FIRST = 1 + 16, FL_SECOND = 1 + 2 + 8 + 16 + 32,
-                      FL_PENULT = 2 + 4 + 8 + 32, FL_LAST = 4;
-        // Scalars that advance by one 32-key block per iteration (kept incremental: the loop is issue-bound and every
-        // scalar instruction between two MFMAs costs a slot): byte offset of K block ii+4 and of V block ii+2 inside
-        // their buffer resources (blocks past the keys only ever exceed num_records: zero fill), first key of block ii.
-        // Block b -> b+1 advances 32 rows, or 96 when b is odd and the key halves interleave (KG = 2).
-        const unsigned k_lo = 32u * k_ts2, v_lo = 32u * v_ts2;
-        const unsigned k_hi = KG == 2 ? 96u * k_ts2 : k_lo, v_hi = KG == 2 ? 96u * v_ts2 : v_lo;
-        unsigned kso = (unsigned)row0_of(3) * k_ts2, vso = (unsigned)row0_of(1) * v_ts2;
-        int kwv = kwave + (KG == 2 ? -96 : -32);
-#define HYD_IT(R, FLV, SW, SR, PW, PR)                                                                       \
-    {                                                                                                        \
-        iter(HYD_IC(slot_k((R) & 3)), HYD_IC(slot_v(((R) + 2) & 3)), HYD_IC(slot_k(((R) + 1) & 3)),          \
-             HYD_IC(slot_v(((R) + 3) & 3)), HYD_IC(FLV), HYD_IC(1), SW, SR, PW, PR, kwv, true,               \
-             __builtin_amdgcn_readfirstlane(kso), __builtin_amdgcn_readfirstlane(vso),                        \
-             slot_k(((R) + 3) & 3), slot_v(((R) + 1) & 3));                                                  \
-        /* ii = i0 + R is odd <=> R even: blocks ii, ii+2, ii+4 share its parity */                          \
-        kso += ((R) & 1) ? k_lo : k_hi;                                                                      \
-        vso += ((R) & 1) ? v_lo : v_hi;                                                                      \
-        kwv += ((R) & 1) ? 32 : (KG == 2 ? 96 : 32);                                                         \
-        dma_wait_w<2 * NLB>();                                                                               \
-        if (!(ABL & 16)) __builtin_amdgcn_s_barrier();                                                       \
-    }
-        int i0 = -1;
-        HYD_IT(0, FL_FIRST, S0, S1, P1, P0)
-        HYD_IT(1, FL_SECOND, S1, S0, P0, P1)
-        for (;;) {
-            if (i0 + 4 >= NB) {
-                HYD_IT(2, FL_PENULT, S0, S1, P1, P0)
-                HYD_IT(3, FL_LAST, S1, S0, P0, P1)
-                break;
-            }
-            HYD_IT(2, FL_FULL, S0, S1, P1, P0)
-            HYD_IT(3, FL_FULL, S1, S0, P0, P1)
-            i0 += 4;
-            if (i0 + 2 >= NB) {
-                HYD_IT(0, FL_PENULT, S0, S1, P1, P0)
-                HYD_IT(1, FL_LAST, S1, S0, P0, P1)
-                break;
-            }
-            HYD_IT(0, FL_FULL, S0, S1, P1, P0)
-            HYD_IT(1, FL_FULL, S1, S0, P0, P1)
-        }
-#undef HYD_IT
-        dma_wait_w<0>();
-        __syncthreads();  // nothing in flight, everyone done with the rings before the merge reuses them
-    }
-    acc_drain();
-    stampk(3);
-#undef HYD_IC
-
-    // ---- merge the two key halves through LDS (KG = 2), normalise, store ------------------------------------
-    // Both waves of a pair (same rows, key half 0 / 1) take part: the wave of key half h finalises the d blocks
-    // [h * NDB/2, (h+1) * NDB/2) of both query blocks and hands the other d blocks (+ its m, l) to its partner through
-    // LDS.  A lane holds 4 consecutive d per (d block, q4); v_permlane32_swap pairs the two half-waves' groups so that
-    // each lane stores 16 contiguous bytes (row-per-lane stores are issue-bound).
-    constexpr int HDB = KG == 2 ? NDB / 2 : NDB;  // d blocks this wave finalises
-    float l_tot[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) l_tot[qb] = pair_sum(l_run[qb]);
-    f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [4 waves][QB][HDB * 4][64 lanes] of f32x4 (64 KB at D = 128)
-    if constexpr (KG == 2) {
-        static_for<QB * HDB>([&](auto I_) __attribute__((always_inline)) {
-            constexpr int qb = decltype(I_)::value / HDB, i = decltype(I_)::value % HDB;
-            float ob[16];  // the d block this wave hands to its partner
-            if (kg) OAcc<qb * NDB + i>::read(ob);
-            else OAcc<qb * NDB + HDB + i>::read(ob);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                f32x4 x = {ob[4 * q4], ob[4 * q4 + 1], ob[4 * q4 + 2], ob[4 * q4 + 3]};
-                obuf[((wave * QB + qb) * HDB * 4 + i * 4 + q4) * 64 + lane] = x;
-            }
-        });
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            mlbuf[(wave * QB + qb) * 128 + lane] = m_raw[qb] * sc;
-            mlbuf[(wave * QB + qb) * 128 + 64 + lane] = l_tot[qb];
-        }
-        __syncthreads();
-    }
-    stampk(4);
-    const int pw = wave ^ 2;  // partner wave (KG = 2)
-    static_for<QB>([&](auto B_) __attribute__((always_inline)) {
-        constexpr int qb = decltype(B_)::value;
-        const float m1 = KG == 2 ? mlbuf[(pw * QB + qb) * 128 + lane] : -INFINITY;
-        const float l1 = KG == 2 ? mlbuf[(pw * QB + qb) * 128 + 64 + lane] : 0.f;
-        const float m_own = m_raw[qb] * sc;  // base-2 exponent units
-        const float mf = fmaxf(m_own, m1);
-        const float mfs = (mf == -INFINITY) ? 0.f : mf;
-        const float a0 = fast_exp2(m_own - mfs), a1 = fast_exp2(m1 - mfs);
-        const float lf = l_tot[qb] * a0 + l1 * a1;
-        const float inv = lf > 0.f ? 1.0f / lf : 0.f;
-        const float w0 = a0 * inv, w1 = a1 * inv;
-        const int64_t obase = (int64_t)sp * a.out_split_stride + row_off[qb];
-        static_for<HDB>([&](auto D_) __attribute__((always_inline)) {
-            constexpr int i = decltype(D_)::value;
-            float ob[16];  // a d block this wave finalises
-            if (KG == 2 && kg) OAcc<qb * NDB + NDB - HDB + i>::read(ob);
-            else OAcc<qb * NDB + i>::read(ob);
-            const int db = KG == 2 ? kg * HDB + i : i;
-            f32x4 x[4];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                if constexpr (KG == 2) {
-                    const f32x4 y = obuf[((pw * QB + qb) * HDB * 4 + i * 4 + q4) * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[q4][j] = ob[4 * q4 + j] * w0 + y[j] * w1;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[q4][j] = ob[4 * q4 + j] * w0;
-                }
-            }
-            if (a.out_f32) {
-                if (rvalid[qb]) {
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + obase + 32 * db + 8 * q4 + 4 * hi) = x[q4];
-                }
-            } else {
-#pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    // groups (2qp, 2qp+1): after the swaps the lower half-wave holds d [8*(2qp), +8), the upper [8*(2qp+1), +8)
-                    u32x4 w;
-#pragma unroll
-                    for (int dw = 0; dw < 2; ++dw) {
-                        const unsigned ea = TR::pack2(x[2 * qp][2 * dw], x[2 * qp][2 * dw + 1]);
-                        const unsigned eb = TR::pack2(x[2 * qp + 1][2 * dw], x[2 * qp + 1][2 * dw + 1]);
-                        auto r2 = __builtin_amdgcn_permlane32_swap(ea, eb, false, false);
-                        w[dw] = r2[0];      // lower half: own group 2qp      | upper half: lower's group 2qp+1
-                        w[2 + dw] = r2[1];  // lower half: upper's group 2qp  | upper half: own group 2qp+1
-                    }
-                    if (rvalid[qb])
-                        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(a.out) + obase + 32 * db + 8 * (2 * qp + hi)) = w;
-                }
-            }
-        });
-        if (a.lse && kg == 0 && hi == 0 && rvalid[qb]) {
-            const float lse = lf > 0.f ? mf * kLn2 + __logf(lf) : -INFINITY;
-            int64_t idx;
-            if (a.lse_layout == HYD_LSE_BQH)
-                idx = (int64_t)(q_tok0 + rtok[qb]) * a.Hq + hq[qb];
-            else
-                idx = ((int64_t)gi * a.Hq + hq[qb]) * a.lse_q_stride + rtok[qb];
-            a.lse[(int64_t)sp * a.lse_split_stride + idx] = lse;
-        }
-    });
-    if constexpr ((ABL & 2048) != 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stampk(5);
-        if (blockIdx.x == 0 && lane < 6) {
-            unsigned tv = tst[0];
-            for (int q_ = 1; q_ < 6; ++q_) tv = lane == q_ ? tst[q_] : tv;
-            reinterpret_cast<unsigned*>(a.lse)[(size_t)a.B * a.nq * a.Hq + wave * 8 + lane] = tv;
-        }
-    }
-}
-
 // One workgroup per unit (grid == a.vgrid), or -- when the caller asks for fewer workgroups than units -- persistent
-// workgroups that walk the units with a stride of the grid: how the shared phase is confined to a part of the chip
-// while the unique phase streams on the rest of it (hyd_decode_params.aux_stream).
+// workgroups that walk the units with a stride of the grid (development switch HYD_PREFIX_PERSIST; the co-run kernel
+// of corun_attn.hip hands units to its prefix role through a queue instead).
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
 __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

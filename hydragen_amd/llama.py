@@ -678,8 +678,14 @@ class HydragenLlamaForCausalLM(nn.Module):
             return  # the first token comes from the prefill logits: no decode step runs
         room = self.model.layers[0].self_attn.kv_cache.per_completion_k_cache.shape[1]
         last_pos = int(start_positions.max().item()) + new_tokens - 2
-        shared = 0 if self.model.get_disable_hydragen() else int(self.get_shared_cache_len(start_positions.shape[0]).min().item())
-        last_idx = last_pos - shared
+        # cache index = position - shared length, PER SEQUENCE (llama.py:487-492 of the reference): with ragged shared
+        # levels the longest position and the shortest shared length belong to different sequences
+        starts = start_positions.reshape(start_positions.shape[0], -1)[:, 0]
+        if self.model.get_disable_hydragen():
+            first_idx = starts
+        else:
+            first_idx = starts - self.get_shared_cache_len(start_positions.shape[0]).to(starts.device)
+        last_idx = int(first_idx.max().item()) + new_tokens - 2
         if last_idx >= room:
             raise ValueError(f"unique cache holds {room} tokens per sequence, decoding needs {last_idx + 1}")
         if last_pos >= self.config.max_position_embeddings:

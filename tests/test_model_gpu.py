@@ -137,6 +137,21 @@ def test_decode_logits_vs_fp32_transformer(dtype, graph, spec):
         assert rdiff(got, want).mean() < (0.05 if dtype == torch.float16 else 0.15), spec
 
 
+def test_generate_room_check_is_per_sequence():
+    """Right-padded shared prompts of lengths [9, 5], fan-out, 16 new tokens, a unique cache of exactly 16 tokens: every
+    sequence's last cache index is 14, so the call fits (the reference, llama.py:1156-1396, has no such check at all).
+    A check built from max(position) - min(shared length) refused it."""
+    model = make_model(torch.bfloat16, head_dim=128)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    ids = [torch.randint(1, 512, (2, 9), device=DEV, generator=g)]
+    lens = [torch.tensor([9, 5], device=DEV)]
+    model.setup_caches(max_unique_batch_size=4, max_unique_seq_length=16, max_shared_batch_sizes=[2], max_shared_seq_lengths=[9])
+    out = model.generate(input_ids=ids, seq_lens=lens, num_return_sequences=2, max_new_tokens=16, temperature=0.0)
+    assert out.shape == (4, 16)
+    with pytest.raises(ValueError, match="unique cache holds"):
+        model.generate(input_ids=ids, seq_lens=lens, num_return_sequences=2, max_new_tokens=18, temperature=0.0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_hydragen_vs_nosharing_and_flat_hierarchy(dtype):
     # fp16: the reference's bound (tests/test_e2e.py:210,298); bf16: scaled for its 3 fewer mantissa bits

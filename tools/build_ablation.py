@@ -9,13 +9,13 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 src, out = REPO / "hydragen_amd" / "csrc", REPO / "build_probe"
 out.mkdir(exist_ok=True)
-srcs = ["api.hip", "prefix_attn_w64.hip", "prefix_attn_pl.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
+srcs = ["api.hip", "prefix_attn_w64.hip", "prefix_attn_pl.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "corun_attn.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DHYD_ABLATION_BUILD", "-Wno-unused-function"]
 
 
 def cc(f):
     o = out / (Path(f).stem + ".o")
-    if o.exists() and o.stat().st_mtime > max((src / f).stat().st_mtime, (src / "hyd_kernels.h").stat().st_mtime, (src / "hyd_common.h").stat().st_mtime):
+    if o.exists() and o.stat().st_mtime > max([(src / f).stat().st_mtime] + [h.stat().st_mtime for h in src.glob("*.h")]):
         return str(o)
     r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-c", str(src / f), "-o", str(o)], capture_output=True, text=True)
     if r.returncode:
