@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-protocol", action="store_true", help="skip the graph + flush reference-protocol sweep")
     ap.add_argument("--no-model", action="store_true", help="skip the Llama-2-7B decode tokens/s leg")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--trials", type=int, default=3, help="repetitions of the K-step schedule after the headline region (spread)")
     ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--model-new-tokens", type=int, default=128)
@@ -140,6 +141,21 @@ class Ops:
         self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][2]), stream))
 
 
+def _respawn(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run, one
+    rank per GPU on this node (the bootstrap of /root/reference/hydragen/utils.py:118-133 reads the same environment)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -147,8 +163,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_respawn(args.gpus))  # plain `python bench.py --gpus N`: start the N ranks ourselves
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU; there is no CPU fallback for the product path"
     # Self-test knobs (not used by the driver): HYD_BENCH_BACKEND=gloo + HYD_BENCH_ONE_DEVICE=1 run the
     # N > 1 control flow with every rank on cuda:0 (RCCL refuses two ranks on one device).
@@ -233,6 +249,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- spread: the same K-step schedule again, `--trials` times, without events (the headline stays trial 0 above) ----
+    trial_us = []
+    for _ in range(args.trials):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(sched[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_ = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        trial_us.append(dt_ / args.steps * 1e6)
+
     # ---- per-kernel durations from the HIP events recorded inside the timed region ----------
     e = 2
     pre_ms = [ev[0].elapsed_time(ev[1]) for ev in events]
@@ -301,6 +336,9 @@ def main():
         "events": {"steps_with_events": n_ev, "rule": "steps i with i % 4 in (1, 2)" if n_ev < args.steps else "every step",
                    "suffix_lens": sched_ev, "suffix_len_mean": sum(sched_ev) / n_ev,
                    "why": "3 event records per step cost 10.5 us of a 217 us step; per-kernel durations are from these steps"},
+        "trials": {"headline": "trial 0 = the timed region above (HIP events on half of its steps)", "trial0_us_per_step": elapsed / args.steps * 1e6,
+                   "repeat_us_per_step": trial_us, "repeat_note": "same schedule, no events, each bracketed like the headline",
+                   **({"repeat_mean_us": sum(trial_us) / len(trial_us), "repeat_min_us": min(trial_us), "repeat_max_us": max(trial_us)} if trial_us else {})},
         "suffix_frac_by_suffix_len": buckets,
         "roofline": suffix_roof if dominant_is_suffix else prefix_roof,
         "roofline_other": prefix_roof if dominant_is_suffix else suffix_roof,
@@ -324,7 +362,7 @@ def main():
         ns = res["reference_protocol"].get("nosharing_speedup_mean")
         if ns is not None:
             res["nosharing_speedup"] = ns
-    if solo and not args.no_accuracy:
+    if rank == 0 and not args.no_accuracy:
         res["accuracy"] = accuracy(ops, q, sk, sv, k, v, S // 2)
     if solo and not args.no_model:
         del ops
@@ -334,8 +372,8 @@ def main():
             res["decode_tokens_per_sec"] = res["model_decode"]["decode_tokens_per_s"]
         except Exception as ex:  # the attention line above must survive a failure of the model leg
             res["model_decode"] = {"error": f"{type(ex).__name__}: {ex}"}
-    if solo and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(B, P, Hq, Hkv, D, args.cpu_seconds)
+    if rank == 0 and not args.no_cpu_baseline:  # whole-job head counts, so that it compares with `value` at any N
+        res["cpu_baseline"] = cpu_baseline(B, P, args.qheads, args.kvheads, D, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(res))
         sys.stdout.flush()
@@ -566,22 +604,32 @@ def model_decode(B, P, new_tokens):
     model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=new_tokens + 16, max_shared_batch_sizes=[1],
                        max_shared_seq_lengths=[P])
 
-    def run(n):
+    def run(n, **kw):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model.generate(input_ids=prompt, num_return_sequences=B, max_new_tokens=n, temperature=100.0)
+        model.generate(input_ids=prompt, num_return_sequences=B, max_new_tokens=n, temperature=100.0, **kw)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    run(4)  # warm-up incl. graph capture
-    full = min(run(new_tokens) for _ in range(2))
-    pre = min(run(1) for _ in range(2))
-    dec = full - pre
+    def mode(**kw):
+        run(4, **kw)  # warm-up incl. graph capture
+        full = min(run(new_tokens, **kw) for _ in range(2))
+        pre = min(run(1, **kw) for _ in range(2))
+        return full, pre, full - pre
+
+    full, pre, dec = mode()
+    # upper bound of scripts/synth.py:111-115 ("noattention": attention replaced by identity on q, llama.py:433-437)
+    _, _, dec_na = mode(disable_attention=True)
+    steps = new_tokens - 1
+    layers = cfg.num_hidden_layers
     return {
         "model": "Llama-2-7B architecture, random weights, bf16, HIP-graph decode", "batch": B, "prefix": P,
         "new_tokens": new_tokens, "total_s": full, "prefill_s": pre, "decode_s": dec,
-        "decode_tokens_per_s": B * (new_tokens - 1) / dec, "ms_per_decode_step": dec / (new_tokens - 1) * 1e3,
-        "protocol": "scripts/synth.py:33-79,207-226",
+        "decode_tokens_per_s": B * steps / dec, "ms_per_decode_step": dec / steps * 1e3,
+        "noattention": {"decode_s": dec_na, "decode_tokens_per_s": B * steps / dec_na, "ms_per_decode_step": dec_na / steps * 1e3},
+        "fraction_of_noattention_bound": dec_na / dec,
+        "attention_us_per_layer_step": (dec - dec_na) / steps / layers * 1e6,
+        "protocol": "scripts/synth.py:33-79,111-115,207-226 (modes hydragen and noattention)",
     }
 
 
@@ -593,8 +641,9 @@ def cpu_baseline(B, P, Hq, Hkv, D, budget_s):
     cores = max(1, logical // 2) if logical > 16 else logical  # physical cores (SMT siblings only add contention)
     torch.set_num_threads(cores)
     S = 64
-    # sample: a slice of the batch (all heads, full prefix, mid suffix), sized to the time budget
-    bs = 128
+    # the decomposed form fits the host (2 GiB of fp32 unique K/V at C2) and is timed on the WHOLE batch;
+    # the time budget bounds the number of iterations, not the workload
+    bs = B
     g = torch.Generator().manual_seed(0)
     q = torch.randn(bs, 1, Hq, D, generator=g)
     k = torch.randn(bs, S, Hkv, D, generator=g)
@@ -611,6 +660,7 @@ def cpu_baseline(B, P, Hq, Hkv, D, budget_s):
         if time.perf_counter() - t0 > budget_s / 2 or n >= 50:
             break
     t_dec = (time.perf_counter() - t0) / n
+    c1 = _cpu_c1(port)
     # no-sharing form on a smaller slice (it is ~P/S times more work per sequence)
     bn = 16
     t1 = time.perf_counter()
@@ -623,12 +673,40 @@ def cpu_baseline(B, P, Hq, Hkv, D, budget_s):
     t_ns = (time.perf_counter() - t1) / m
     return {
         "value": bs / t_dec, "unit": "tokens/s", "cores": cores, "kind": "port",
-        "sample": f"decomposed attention (torch CPU fp32, {cores} threads) on {bs} of {B} sequences, all {Hq} heads, "
-                  f"prefix {P}, suffix {S}; {n} iterations; tokens/s = sequences / time per step",
+        "sample": f"decomposed attention (torch CPU fp32, {cores} threads) on all {bs} sequences, all {Hq} heads, "
+                  f"prefix {P}, suffix {S} (the mean of the GPU schedule); {n} iterations of the whole step; tokens/s = {bs} / time per step",
+        "c1_full": c1,
         "nosharing_tokens_per_sec": bn / t_ns,
         "nosharing_sample": f"no-sharing SDPA over concatenated KV on {bn} sequences (stride-0 expanded prefix), {m} iterations",
         "cpu_model": _cpu_model(),
     }
+
+
+def _cpu_c1(port):
+    """BASELINE config 1 literal (batch 4, prefix 64, suffix 8, 4 heads, dim 64), the reference's CPU-runnable case, in full."""
+    g = torch.Generator().manual_seed(1)
+    q, k, v = torch.randn(4, 1, 4, 64, generator=g), torch.randn(4, 8, 4, 64, generator=g), torch.randn(4, 8, 4, 64, generator=g)
+    sk, sv = torch.randn(1, 64, 4, 64, generator=g), torch.randn(1, 64, 4, 64, generator=g)
+    sl = torch.full((4,), 8, dtype=torch.int64)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)  # 70 kFLOP: threads only add wake-up latency
+    try:
+        for _ in range(20):
+            port.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
+        n, t0 = 500, time.perf_counter()
+        for _ in range(n):
+            port.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
+        t = (time.perf_counter() - t0) / n
+        for _ in range(20):
+            port.nosharing_attention(q, k, v, sk, sv, sl)
+        t1 = time.perf_counter()
+        for _ in range(n):
+            port.nosharing_attention(q, k, v, sk, sv, sl)
+        tn = (time.perf_counter() - t1) / n
+    finally:
+        torch.set_num_threads(nt)
+    return {"config": "batch 4, prefix 64, suffix 8, 4/4 heads, d=64, fp32, 1 thread, 500 iterations", "decomposed_us": t * 1e6,
+            "nosharing_us": tn * 1e6, "tokens_per_s": 4 / t}
 
 
 def _cpu_model():

@@ -89,7 +89,7 @@ class AllReduceParams(C.Structure):
     _fields_ = [
         ("blocks", C.POINTER(C.c_void_p)), ("in_", C.c_void_p), ("out", C.c_void_p), ("count", C.c_int64),
         ("max_bytes", C.c_size_t), ("dtype", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
-        ("reserved", C.c_int32),
+        ("timeout_log2_polls", C.c_int32),
     ]
 
 
@@ -117,6 +117,7 @@ EXPORTS = {
 }
 
 _lib = None
+ABI_VERSION = 202  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
 
 
 def lib_path() -> Path:
@@ -148,6 +149,11 @@ def load():
             raise HydragenLibraryError(f"{p} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    got = lib.hyd_version()
+    if got != ABI_VERSION:  # the struct mirrors above are those of exactly this header version
+        raise HydragenLibraryError(
+            f"{p} is ABI {got // 100}.{got // 10 % 10}.{got % 10}, the Python mirrors are "
+            f"{ABI_VERSION // 100}.{ABI_VERSION // 10 % 10}.{ABI_VERSION % 10}: rebuild it (python hydragen_amd/csrc/build.py --force)")
     _lib = lib
     return lib
 

@@ -12,6 +12,7 @@ allocation inside the library.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional
 
 import torch
@@ -181,10 +182,13 @@ def _level_pass(q, sk, sv, scu, smax, use_varlen):
     )
 
 
-# Marshalled `hyd_decode_params` + workspace per (tensor set, shapes): an eager call then costs one dict lookup, one
-# `torch.empty_like` and one C call instead of ~20 us of ctypes field stores (under HIP graphs the host path does not
-# run at all).  Keys hold only addresses / shapes / strides, values hold no tensor except the scratch workspace, so a
-# stale entry can at worst describe memory the caller no longer passes in -- it is then simply never looked up again.
+# Marshalled `hyd_decode_params` + workspace per (tensor set, shapes, stream, thread): an eager call then costs one dict
+# lookup, one `torch.empty_like` and one C call instead of ~20 us of ctypes field stores (under HIP graphs the host path
+# does not run at all).  An entry's struct is mutated on every hit (`suffix.out`) and its scratch workspace is written
+# by the launch, so entries are private to the (stream, thread) that made them: two streams or two threads never share
+# a struct or a workspace.  Values keep alive the scratch workspace and the (contiguous) length tensors the struct
+# points at; a stale entry can at worst describe memory the caller no longer passes in -- it is then never looked up
+# again.
 _PARAM_CACHE: dict = {}
 _PARAM_CACHE_MAX = 64
 _PARAM_CACHE_MAX_BYTES = 256 << 20  # scratch held by cached entries
@@ -199,17 +203,19 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
     lib = _lib.load()
     b, nq, hq, d = q.shape
     out = torch.empty_like(q)
-    capturing = torch.cuda.is_current_stream_capturing() or _flash._SCALE != 0.0  # padded temporaries: nothing to cache
+    # no cache while capturing (the scratch belongs to the graph's private pool) or with a head-dim override (padded temporaries)
+    uncached = torch.cuda.is_current_stream_capturing() or _flash.current_softmax_scale() != 0.0
     key = None
-    if not capturing:  # a captured call keeps its scratch in the graph's private pool instead
-        key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), q.device.index,
+    stream = _stream()
+    if not uncached:
+        key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), q.device.index, stream, threading.get_ident(),
                tuple(_tensor_key(x) for x in shared_ks), tuple(_tensor_key(x) for x in shared_vs),
                tuple(_tensor_key(x) for x in shared_cu_seq_lens), tuple(shared_max_seq_lens), tuple(use_varlens))
         hit = _PARAM_CACHE.get(key)
         if hit is not None:
             p = hit[0]
             p.suffix.out = out.data_ptr()
-            _lib.check(lib.hyd_decode_attn_fused(C.byref(p), _stream()))
+            _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
             return out
     p = DecodeParams()
     keep = [fill_suffix_params(p.suffix, q, k, v, seq_lens, out)]
@@ -228,7 +234,7 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         keep.append(ws)
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
-    _lib.check(lib.hyd_decode_attn_fused(C.byref(p), _stream()))
+    _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
     # cache only when every pointer in `p` refers to caller-owned memory or to tensors `keep` holds on to
     cacheable = key is not None and (seq_lens is None or seq_lens.dtype in (torch.int32, torch.int64)) and \
         all(x is None or x.is_contiguous() for x in shared_cu_seq_lens) and (seq_lens is None or seq_lens.is_contiguous())

@@ -28,9 +28,9 @@ constexpr int kArMaxWorld = 8;
 constexpr int kArFlagStride = 32;           // uint32 words per flag (128 B: one flag per cache line)
 constexpr int kArFlagWords = 2 * kArMaxWorld * kArFlagStride;  // two phases x world flags
 constexpr int kArLocalWords = 64;           // epoch, arrival counter, status (never read by peers)
-constexpr size_t kArHeaderBytes = (kArFlagWords + kArLocalWords) * sizeof(uint32_t);  // 2304 B -> padded to 4 KiB
-constexpr size_t kArHeaderPad = 4096;
-constexpr uint32_t kArSpinLimit = 1u << 24;  // polls; one poll (s_sleep 8 + a flag load) measured at ~0.3 us: ~5 s
+constexpr size_t kArHeaderPad = 4096;       // flags + local words = 2304 B, padded
+static_assert((kArFlagWords + kArLocalWords) * sizeof(uint32_t) <= kArHeaderPad, "header");
+constexpr int kArSpinLog2Default = 27;      // polls per wait; one poll (s_sleep 8 + a flag load) measured at ~0.3 us: ~40 s
 
 struct ArArgs {
     char* block[kArMaxWorld];  // every rank's shared block as mapped in this process; block[rank] is our own
@@ -40,6 +40,7 @@ struct ArArgs {
     int64_t slice;             // elements per rank slice (multiple of 8, slice * world >= count)
     size_t stage_bytes;        // bytes reserved for `staged input` inside a block
     int32_t rank, world, dtype;
+    uint32_t spin_limit;       // polls per wait before a rank gives up (status word)
 };
 
 __device__ __forceinline__ uint32_t* flag_ptr(char* block, int phase, int from) {
@@ -49,11 +50,11 @@ __device__ __forceinline__ uint32_t* local_ptr(char* block, int i) {
     return reinterpret_cast<uint32_t*>(block) + kArFlagWords + i;
 }
 
-// one lane waits until *flag >= epoch; returns false after kArSpinLimit polls.  The bound counts polls, not clock
+// one lane waits until *flag >= epoch; returns false after spin_limit polls.  The bound counts polls, not clock
 // ticks: a wave that the scheduler saves and restores (several processes sharing one device) can resume on another
 // XCD, whose s_memtime has a different base -- a clock difference across that switch reads as an instant timeout.
-__device__ __forceinline__ bool wait_flag(uint32_t* flag, uint32_t epoch) {
-    for (uint32_t n = 0; n < kArSpinLimit; ++n) {
+__device__ __forceinline__ bool wait_flag(uint32_t* flag, uint32_t epoch, uint32_t spin_limit) {
+    for (uint32_t n = 0; n < spin_limit; ++n) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) return true;
         __builtin_amdgcn_s_sleep(8);
     }
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
     const uint32_t epoch = s_epoch;
     // ---- wait for every rank's staged input (announced by the stage kernels) ---------------------------------
     if (tid < a.world) {
-        if (!wait_flag(flag_ptr(mine, 0, tid), epoch)) s_ok = 0;
+        if (!wait_flag(flag_ptr(mine, 0, tid), epoch, a.spin_limit)) s_ok = 0;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
     // ---- shot 2: gather every peer's reduced slice ----------------------------------------------------------
     for (int q = 1; q < a.world; ++q) {
         const int p = (a.rank + q) % a.world;  // start with a different peer on every rank: all links busy
-        if (tid == 0) s_ok = wait_flag(flag_ptr(mine, 1, p), epoch) ? 1u : 0u;
+        if (tid == 0) s_ok = wait_flag(flag_ptr(mine, 1, p), epoch, a.spin_limit) ? 1u : 0u;
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         const bool ok2 = s_ok != 0;
@@ -235,7 +236,7 @@ size_t allreduce_block_bytes(int world, size_t max_bytes) {
 }
 
 int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, void* out, int64_t count, int dtype,
-                     int rank, int world, size_t max_bytes, hipStream_t s) {
+                     int rank, int world, size_t max_bytes, int timeout_log2_polls, hipStream_t s) {
     ArArgs a;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < world; ++i) a.block[i] = blocks[i];
@@ -249,6 +250,7 @@ int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, vo
     a.rank = rank;
     a.world = world;
     a.dtype = dtype;
+    a.spin_limit = 1u << (timeout_log2_polls > 0 ? timeout_log2_polls : kArSpinLog2Default);
     (void)block_bytes;
     const size_t bytes = (size_t)count * elt;
     // few workgroups on purpose: the kernel waits on its peers, so every workgroup must be resident while it spins

@@ -572,6 +572,8 @@ int hyd_allreduce_sum(const hyd_allreduce_params* p, void* stream) {
     if (p->rank < 0 || p->rank >= p->world) return fail(HYD_ERR_BAD_ARG, "rank %d of %d", p->rank, p->world);
     if (p->dtype != HYD_F16 && p->dtype != HYD_BF16 && p->dtype != HYD_F32) return fail(HYD_ERR_UNSUPPORTED, "dtype %d", p->dtype);
     if (p->count < 0) return fail(HYD_ERR_BAD_ARG, "count %lld", (long long)p->count);
+    if (p->timeout_log2_polls != 0 && (p->timeout_log2_polls < 10 || p->timeout_log2_polls > 31))
+        return fail(HYD_ERR_BAD_ARG, "timeout_log2_polls %d (0 = default, or 10..31)", p->timeout_log2_polls);
     if (p->count == 0) return HYD_OK;
     const size_t bytes = (size_t)p->count * (p->dtype == HYD_F32 ? 4 : 2);
     if (bytes > p->max_bytes) return fail(HYD_ERR_WORKSPACE, "%zu bytes exceed the blocks' max_bytes %zu", bytes, p->max_bytes);
@@ -587,7 +589,7 @@ int hyd_allreduce_sum(const hyd_allreduce_params* p, void* stream) {
         return HYD_OK;
     }
     rc = launch_allreduce(blocks, allreduce_block_bytes(p->world, p->max_bytes), p->in, p->out, p->count, p->dtype, p->rank,
-                          p->world, p->max_bytes, static_cast<hipStream_t>(stream));
+                          p->world, p->max_bytes, p->timeout_log2_polls, static_cast<hipStream_t>(stream));
     return rc ? fail(HYD_ERR_LAUNCH, "all-reduce kernel launch failed: hip error %d", rc) : HYD_OK;
 }
 

@@ -15,10 +15,10 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SOURCES = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "corun_attn.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
-HEADERS = ["hyd_common.h", "hyd_kernels.h", "suffix_common.h", "suffix_stream.h", "prefix_unit_w64.h", "../../include/hydragen_hip.h"]
+HEADERS = sorted(h.name for h in HERE.glob("*.h")) + ["../../include/hydragen_hip.h"]
 LIB = HERE / "libhydragen_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Werror", "-Wno-unused-function"]
 if os.environ.get("HYD_ABLATION_BUILD"):  # development only: A/B switches + the superseded round-1 prefix kernel
     FLAGS.append("-DHYD_ABLATION_BUILD")
     SOURCES.append("prefix_attn_pl.hip")

@@ -101,6 +101,6 @@ int launch_suffix_gqa_stream(const SuffixArgs& a, int dtype, unsigned* queue, in
 int launch_suffix_stream_dev(const SuffixArgs& sa, int dtype, int grid, int upi, int nbuf, hipStream_t s);  // ablation builds only
 size_t allreduce_block_bytes(int world, size_t max_bytes);
 int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, void* out, int64_t count, int dtype,
-                     int rank, int world, size_t max_bytes, hipStream_t s);
+                     int rank, int world, size_t max_bytes, int timeout_log2_polls, hipStream_t s);
 
 }  // namespace hyd

@@ -11,6 +11,7 @@ PyTorch is used for device memory and the current stream only.
 
 from __future__ import annotations
 
+import contextvars
 import ctypes as C
 
 import torch
@@ -72,7 +73,13 @@ def _q_contig(q: Tensor) -> Tensor:
 # the TRUE head dim's softmax scale (hyd_*_params.softmax_scale): zero columns add nothing to q.k and produce zero
 # output columns, which are cut off again.  Functional, not fast: q, k and v are copied on every call -- a model with
 # such a head dim should keep its caches padded instead.
-_SCALE = 0.0  # forwarded to the C ABI by the marshalling helpers below; 0 = head_dim ** -0.5
+# forwarded to the C ABI by the marshalling helpers below; 0 = head_dim ** -0.5.  A context variable: two threads (or
+# tasks) serving models with different head dims each see their own value.
+_scale_var: contextvars.ContextVar = contextvars.ContextVar("hydragen_amd_softmax_scale", default=0.0)
+
+
+def current_softmax_scale() -> float:
+    return _scale_var.get()
 
 
 def padded_head_dim(d: int) -> int:
@@ -94,12 +101,10 @@ class true_head_dim_scale:
         self.scale = float(d) ** -0.5
 
     def __enter__(self):
-        global _SCALE
-        self.prev, _SCALE = _SCALE, self.scale
+        self.token = _scale_var.set(self.scale)
 
     def __exit__(self, *exc):
-        global _SCALE
-        _SCALE = self.prev
+        _scale_var.reset(self.token)
 
 
 def prefix_attention(
@@ -133,7 +138,7 @@ def prefix_attention(
     p.causal = 1 if causal else 0
     p.lse_layout = lse_layout
     p.num_splits = num_splits
-    p.softmax_scale = _SCALE
+    p.softmax_scale = _scale_var.get()
     ws_bytes = lib.hyd_prefix_workspace_bytes(C.byref(p))
     ws = None
     if ws_bytes:
@@ -217,7 +222,7 @@ def fill_suffix_params(p: SuffixParams, q: Tensor, k: Tensor, v: Tensor, seq_len
     p.dtype = _dtype_code(q)
     p.B, p.nq, p.Hq, p.Hkv, p.D = b, nq, hq, k.shape[2], d
     p.kv_len = k.shape[1]
-    p.softmax_scale = _SCALE
+    p.softmax_scale = _scale_var.get()
     keep = None
     if seq_len is not None:
         assert seq_len.shape == (b,), f"{seq_len.shape}"

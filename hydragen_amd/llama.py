@@ -25,7 +25,7 @@ from torch import Tensor, nn
 
 from .attention import hydragen_attention
 from .flash import flash_attention, flash_attention_seqlen
-from .tp import all_reduce_sum
+from .tp import all_reduce_sum, check_collectives
 
 
 @dataclass
@@ -766,4 +766,5 @@ class HydragenLlamaForCausalLM(nn.Module):
             tokens.append(nxt)
             feed = nxt if token_overrides is None else token_overrides[:, step + 1 : step + 2]
         out = torch.cat(tokens, dim=-1)
+        check_collectives()  # no-op without the direct xGMI all-reduce; raises if a rank ever gave up on a peer
         return (out, kept_logits) if return_logits else out

@@ -65,6 +65,14 @@ def use_xgmi_allreduce(comm) -> None:
     _xgmi = comm
 
 
+def check_collectives() -> None:
+    """Raise if the direct xGMI all-reduce ever gave up waiting for a peer (RCCL would have waited; the kernel's waits are
+    bounded so that a lost peer cannot hang the device, and a rank that gives up publishes garbage).  Called at the end
+    of every `generate()`; synchronises."""
+    if _xgmi is not None:
+        _xgmi.check()
+
+
 def all_reduce_sum(x: Tensor) -> Tensor:
     """The forward hook of tp.py:108-112 / 83-87.  In place; no-op without a process group."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -55,7 +55,10 @@ _HIP_DEVICE_MALLOC_FINEGRAINED = 0x1
 
 
 class XgmiAllReduce:
-    def __init__(self, max_bytes: int, group=None, device: torch.device | None = None):
+    def __init__(self, max_bytes: int, group=None, device: torch.device | None = None, timeout_log2_polls: int = 0):
+        """timeout_log2_polls: every wait on a peer gives up after 2^n polls of ~0.3 us (0 = the library default, 2^27,
+        ~40 s).  A rank that gives up leaves garbage in its output and sets the block's status word: call `check()`
+        (or `hydragen_amd.tp.check_collectives()`) before trusting the results of a run."""
         assert dist.is_initialized(), "init_process_group first: the IPC handles are exchanged through it"
         self.lib = _lib.load()
         self.group = group
@@ -64,6 +67,7 @@ class XgmiAllReduce:
             raise NotImplementedError("one node: at most 8 ranks")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.max_bytes = int(max_bytes)
+        self.timeout_log2_polls = int(timeout_log2_polls)
         self.block_bytes = self.lib.hyd_allreduce_block_bytes(self.world, self.max_bytes)
         assert self.block_bytes > 0
         hip = _runtime()
@@ -104,6 +108,7 @@ class XgmiAllReduce:
         p.blocks = C.cast(self._blocks, C.POINTER(C.c_void_p))
         p.in_, p.out, p.count = x.data_ptr(), x.data_ptr(), x.numel()
         p.max_bytes, p.dtype, p.rank, p.world = self.max_bytes, _DT[x.dtype], self.rank, self.world
+        p.timeout_log2_polls = self.timeout_log2_polls
         _lib.check(self.lib.hyd_allreduce_sum(C.byref(p), torch.cuda.current_stream().cuda_stream))
         return x
 
@@ -113,6 +118,13 @@ class XgmiAllReduce:
         word = C.c_uint32()
         _runtime().hipMemcpy(C.byref(word), self.lib.hyd_allreduce_status(self._own), 4, 2)  # device -> host
         return int(word.value)
+
+    def check(self) -> None:
+        """Raise if any call so far gave up on a peer (its output was not the sum).  Synchronises the device."""
+        st = self.status()
+        if st:
+            raise RuntimeError(f"xGMI all-reduce: rank {self.rank} gave up waiting for a peer in shot {st} "
+                               f"(2^{self.timeout_log2_polls or 27} polls); results of this run are invalid")
 
     def close(self):
         if getattr(self, "_own", None) is None:

@@ -44,7 +44,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
 #define HYD_API __attribute__((visibility("default")))
 
-#define HYD_VERSION 201 /* 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
+#define HYD_VERSION 202 /* 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
 #define HYD_MAX_LEVELS 8
 
 enum {
@@ -215,15 +215,21 @@ HYD_API int hyd_rope_append_decode(const hyd_rope_params* p, void* stream);
  * peer-mapped device memory: xGMI is a full mesh, so every rank reads its slice straight from every
  * peer (reduce-scatter), then every reduced slice from its owner (all-gather).  One process per GPU.
  *
- * Each rank owns one zero-initialised "shared block" of hyd_allreduce_block_bytes() bytes in device
- * memory obtained from hipMalloc, exports it with hyd_ipc_get_handle, and maps every peer's block with
- * hyd_ipc_open_handle (handles travel over any host channel, e.g. torch.distributed all_gather_object).
+ * Each rank owns one zero-initialised "shared block" of hyd_allreduce_block_bytes() bytes of UNCACHED device
+ * memory -- hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached), or hipDeviceMallocFinegrained where that is
+ * refused; NEVER plain hipMalloc: peers write the block's flags and read its staged payload through the fabric,
+ * which does not probe the owner's L2 for coarse-grained allocations (stale reads) -- exports it with
+ * hyd_ipc_get_handle, and maps every peer's block with hyd_ipc_open_handle (handles travel over any host channel,
+ * e.g. torch.distributed all_gather_object).
  * `blocks` is a HOST array of `world` device pointers: blocks[r] is rank r's block as mapped in THIS
  * process (blocks[rank] is the own block).  `in` / `out` are ordinary device buffers, 16-byte aligned,
  * count * sizeof(dtype) <= max_bytes; in == out is allowed.  Every rank must issue the same sequence of
- * calls.  Capture-safe: the call's epoch lives in the block, not in the arguments.  A peer that does
- * not show up within ~1 s makes the kernel give up (status word != 0, see hyd_allreduce_status) instead
- * of hanging the device.
+ * calls.  Capture-safe: the call's epoch lives in the block, not in the arguments.
+ * Waiting is bounded by a POLL COUNT, 2^timeout_log2_polls polls of ~0.3 us each per wait (0 = the default
+ * 2^27, ~40 s -- longer than any lazy module load, graph capture or shard load between two ranks' calls):
+ * a peer that never shows up makes the kernel give up instead of hanging the device; `out` is then NOT the
+ * sum, and the block's status word (hyd_allreduce_status) is 1 / 2.  The caller MUST read that word before
+ * trusting results of a run (hydragen_amd.tp.check_collectives does, at the end of every generate()).
  * ------------------------------------------------------------------------------------------ */
 #define HYD_IPC_HANDLE_BYTES 64
 #define HYD_ALLREDUCE_MAX_WORLD 8
@@ -239,7 +245,7 @@ typedef struct hyd_allreduce_params {
     size_t max_bytes;     /* the value the blocks were sized with                                  */
     int32_t dtype;        /* HYD_F16 | HYD_BF16 | HYD_F32; accumulation in fp32                    */
     int32_t rank, world;  /* world <= HYD_ALLREDUCE_MAX_WORLD                                      */
-    int32_t reserved;
+    int32_t timeout_log2_polls; /* 0 = default (27); 10..31: each wait gives up after 2^n polls    */
 } hyd_allreduce_params;
 
 HYD_API size_t hyd_allreduce_block_bytes(int32_t world, size_t max_bytes);

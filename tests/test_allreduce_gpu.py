@@ -112,6 +112,7 @@ def test_missing_peer_times_out_with_status():
     p.blocks = C.cast(blocks, C.POINTER(C.c_void_p))
     p.in_, p.out, p.count = x.data_ptr(), x.data_ptr(), x.numel()
     p.max_bytes, p.dtype, p.rank, p.world = max_bytes, HYD_BF16, 0, 2
+    p.timeout_log2_polls = 22  # ~1.3 s per wait instead of the default ~40 s
     t0 = time.time()
     _lib.check(lib.hyd_allreduce_sum(C.byref(p), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()

@@ -1,0 +1,69 @@
+"""bench.py contract checks: `python bench.py --gpus N` without a launcher starts its own N ranks (the driver's N = 1
+command and a future multi-GPU run go through the same entry), and the N > 1 line carries every object of the N = 1 line
+the driver's rules ask for.  The 2-rank run shares the box's one GPU (HYD_BENCH_ONE_DEVICE=1) and all-reduces on gloo
+(RCCL refuses two ranks on one device); sharding follows /root/reference/hydragen/tp.py:90-124."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_respawn_command_line(monkeypatch):
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert bench._respawn(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _run_bench(args, extra_env=None, timeout=600):
+    env = dict(os.environ, **(extra_env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_without_a_launcher():
+    res = _run_bench(["--gpus", "2", "--steps", "8", "--warmup", "2", "--trials", "1", "--cpu-seconds", "2", "--no-xgmi"],
+                     {"HYD_BENCH_BACKEND": "gloo", "HYD_BENCH_ONE_DEVICE": "1"})
+    assert res["n_gpus"] == 2 and res["steps"] == 8 and res["scaling"] == "strong"
+    for key in ("roofline", "roofline_other", "cpu_baseline", "allreduce_us", "rccl_ranks", "trials", "accuracy"):
+        assert key in res, key
+    assert res["rccl_ranks"] == 2 and res["value"] > 0
+    assert res["roofline"]["bound"] in ("hbm", "mfma") and 0 < res["roofline"]["frac"] < 1
+    assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["value"] > 0
+    assert "TP2" in res["config"]["parallelism"].upper()
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_is_complete():
+    res = _run_bench(["--gpus", "1", "--steps", "8", "--warmup", "2", "--trials", "2", "--cpu-seconds", "2", "--no-model",
+                      "--no-protocol"])
+    assert res["n_gpus"] == 1 and res["metric"] == "decode_attention_tokens_per_sec" and res["unit"] == "tokens/s"
+    assert res["vs_baseline"] is None and res["dtype"] == "bf16" and res["data"] == "synthetic"
+    assert len(res["trials"]["repeat_us_per_step"]) == 2
+    assert abs(res["trials"]["trial0_us_per_step"] - res["ms_per_step"] * 1e3) < 1e-6
+    assert set(res["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(res["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "c1_full"}
