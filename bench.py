@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--no-protocol", action="store_true", help="skip the graph + flush reference-protocol sweep")
     ap.add_argument("--no-model", action="store_true", help="skip the Llama-2-7B decode tokens/s leg")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="steps replay the two-stream form of the operator instead of the one-call form (A/B; DESIGN 4.8)")
     ap.add_argument("--trials", type=int, default=3, help="repetitions of the K-step schedule after the headline region (spread)")
     ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -99,46 +101,80 @@ def describe_schedule(sched: list[int]) -> str:
 
 
 class Ops:
-    """Pre-marshalled `hyd_decode_params` per suffix length (one per phase), so a step costs two ctypes calls."""
+    """Pre-marshalled `hyd_decode_params` per suffix length, and per suffix length one captured HIP graph of the
+    operator in its two-stream form (shared phase on a side stream || unique phase, then the merge) -- what
+    `hydragen_attention` issues while the decode loop's graph is captured (hydragen_amd/attention.py::_launch_decode)."""
 
-    def __init__(self, q, k, v, sk, sv, lens_needed):
-        from hydragen_amd import _lib
-        from hydragen_amd._lib import DecodeParams, HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE
+    def __init__(self, q, k, v, sk, sv, lens_needed, two_stream=True):
+        from hydragen_amd import _lib, attention
+        from hydragen_amd._lib import (DecodeParams, HYD_PHASE_ALL, HYD_PHASE_MERGE, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE,
+                                       HYD_PHASE_UNIQUE_PARTIAL)
         from hydragen_amd.attention import _fill_level
         from hydragen_amd.flash import fill_suffix_params
 
         self.lib = _lib.load()
         self._lib = _lib
+        self.two_stream = two_stream
+        self.side = torch.cuda.Stream()
         B = q.shape[0]
         self.out = torch.empty_like(q)
-        self.params, self.keep = {}, []
+        self.params, self.keep, self.graphs = {}, [], {}
         ws_bytes = 0
         for s in sorted(set(lens_needed)):
             sl = torch.full((B,), s, dtype=torch.int32, device=q.device)
-            trio = []
-            for phase in (HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE):
+            ps = {}
+            for phase in (HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE, HYD_PHASE_UNIQUE_PARTIAL, HYD_PHASE_MERGE):
                 p = DecodeParams()
                 fill_suffix_params(p.suffix, q, k, v, sl, self.out)
                 p.n_levels = 1
                 p.phase = phase
                 _fill_level(p.levels[0], sk, sv, None, None, False, B)
-                trio.append(p)
-            ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(trio[0])))
-            self.params[s] = trio
+                ps[phase] = p
+            # the two-stream form's shared phase keeps to half of the chip (persistent prefix workgroups)
+            ps["shared_side"] = DecodeParams.from_buffer_copy(ps[HYD_PHASE_SHARED])
+            ps["shared_side"].shared_max_workgroups = attention.TWO_STREAM_PREFIX_CUS
+            ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(ps[HYD_PHASE_ALL])))
+            self.params[s] = ps
             self.keep.append(sl)
         self.ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=q.device)
-        for trio in self.params.values():
-            for p in trio:
+        for ps in self.params.values():
+            for p in ps.values():
                 p.workspace, p.workspace_bytes = self.ws.data_ptr(), ws_bytes
+        self.PH = (HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE, HYD_PHASE_UNIQUE_PARTIAL, HYD_PHASE_MERGE)
+
+    def _call(self, s, which, stream):
+        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][which]), stream))
 
     def fused(self, s, stream):
-        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][0]), stream))
+        self._call(s, self.PH[0], stream)
 
     def shared_phase(self, s, stream):
-        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][1]), stream))
+        self._call(s, self.PH[1], stream)
 
     def unique_phase(self, s, stream):
-        self._lib.check(self.lib.hyd_decode_attn_fused(C.byref(self.params[s][2]), stream))
+        self._call(s, self.PH[2], stream)
+
+    def two_stream_issue(self, s):
+        """fork: shared phase on the side stream || unique partial on the current stream; join; merge"""
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        self._call(s, "shared_side", self.side.cuda_stream)
+        self._call(s, self.PH[3], main.cuda_stream)
+        main.wait_stream(self.side)
+        self._call(s, self.PH[4], main.cuda_stream)
+
+    def graph(self, s, two_stream=None):
+        """The operator at suffix length s as a captured HIP graph (hydragen/benchmark_utils.py:140-170 captures the
+        operator the same way); two-stream form unless told otherwise."""
+        two = self.two_stream if two_stream is None else two_stream
+        key = (s, two)
+        if key not in self.graphs:
+            fn = (lambda: self.two_stream_issue(s)) if two else (lambda: self.fused(s, torch.cuda.current_stream().cuda_stream))
+            self.graphs[key] = _capture(fn)
+        return self.graphs[key]
+
+    def step(self, s):
+        self.graph(s).replay()
 
 
 def _respawn(n: int) -> int:
@@ -190,7 +226,9 @@ def main():
     sched = suffix_schedule(args.steps, S)
     warm_sched = suffix_schedule(max(args.warmup, 1), S)
     sweep = [s for s in SWEEP if s <= S]
-    ops = Ops(q, k, v, sk, sv, sched + warm_sched + sweep)
+    ops = Ops(q, k, v, sk, sv, sched + warm_sched + sweep, two_stream=args.two_stream)
+    for s_ in sorted(set(sched + warm_sched)):  # capture outside the timed region
+        ops.graph(s_)
     # stand-in for the row-parallel o_proj partial output that tp.py:108-112 all-reduces
     ar_buf = torch.randn(B, 1, hidden, device=dev, dtype=dt) if world > 1 else None
     ar_host = ar_buf.float().cpu() if (world > 1 and backend != "nccl") else None
@@ -203,12 +241,12 @@ def main():
             dist.all_reduce(ar_host)
 
     def step(s, ev=None):
-        if ev is None:
-            ops.shared_phase(s, stream)
-            ops.unique_phase(s, stream)
+        if ev is None:  # the operator as the decode loop runs it: one replay of its captured graph
+            ops.step(s)
             if world > 1:
                 collective()
             return
+        # steps that carry events: the two kernels in order, eagerly, an event before, between and after them
         ev[0].record()
         ops.shared_phase(s, stream)
         ev[1].record()
@@ -222,10 +260,14 @@ def main():
         step(warm_sched[i])
     torch.cuda.synchronize()
 
-    # Events cost: three records per step add 10.5 us to a 217 us step (measured), one barrier packet each.
-    # They are recorded on every other PAIR of steps (i % 4 in {1, 2}): half the steps, and -- the schedule being a
-    # uniform cover -- exactly the mean suffix length of all of them.  Fewer than 8 steps: every step.
-    ev_idx = [i for i in range(args.steps) if i % 4 in (1, 2)] if args.steps >= 8 else list(range(args.steps))
+    # Per-kernel durations need the two kernels one after the other with an event between them, so the steps that carry
+    # events run the operator eagerly IN ORDER (three records cost ~10 us of such a step); all other steps replay the
+    # captured two-stream graph.  Event steps: i % 4 == 1 in the first half of the schedule and their mirror images
+    # K-1-i -- the schedule is a uniform cover, so this subset has exactly the mean suffix length of all K steps.
+    # Fewer than 8 steps: every step.
+    K_ = args.steps
+    ev_idx = sorted({i for i in range(K_ // 2) if i % 4 == 1} | {K_ - 1 - i for i in range(K_ // 2) if i % 4 == 1}) \
+        if K_ >= 8 else list(range(K_))
     nev = 4 if world > 1 else 3
     ev_of = {i: [torch.cuda.Event(enable_timing=True) for _ in range(nev)] for i in ev_idx}
     events = [ev_of[i] for i in ev_idx]
@@ -333,11 +375,18 @@ def main():
         "attn_us_per_step": elapsed / args.steps * 1e6,
         "prefix_us": sum(pre_ms) / n_ev * 1e3,
         "suffix_us_mean": sum(suf_ms) / n_ev * 1e3,
-        "events": {"steps_with_events": n_ev, "rule": "steps i with i % 4 in (1, 2)" if n_ev < args.steps else "every step",
-                   "suffix_lens": sched_ev, "suffix_len_mean": sum(sched_ev) / n_ev,
-                   "why": "3 event records per step cost 10.5 us of a 217 us step; per-kernel durations are from these steps"},
+        "step_forms": {"graph_replay_steps": args.steps - n_ev,
+                       "graph_form": "one-call form (hyd_decode_attn_fused: prefix pass, then suffix pass with the merge in its epilogue)"
+                       if not args.two_stream else
+                       "two-stream form: shared phase (persistent prefix workgroups on half of the CUs) on a side stream || "
+                       "unique phase, join, log-sum-exp merge (hydragen_amd.attention.set_two_stream)",
+                       "eager_in_order_steps_with_events": n_ev},
+        "events": {"steps_with_events": n_ev, "rule": "i % 4 == 1 in the first half of the schedule + mirror images K-1-i" if n_ev < args.steps else "every step",
+                   "steps": ev_idx, "suffix_lens": sched_ev, "suffix_len_mean": sum(sched_ev) / n_ev,
+                   "why": "a kernel's own duration needs the two kernels in order with an event between them; these steps run the "
+                          "operator eagerly in that form, the per-kernel rooflines are theirs"},
         "trials": {"headline": "trial 0 = the timed region above (HIP events on half of its steps)", "trial0_us_per_step": elapsed / args.steps * 1e6,
-                   "repeat_us_per_step": trial_us, "repeat_note": "same schedule, no events, each bracketed like the headline",
+                   "repeat_us_per_step": trial_us, "repeat_note": "same schedule, every step a graph replay, no events, each bracketed like the headline",
                    **({"repeat_mean_us": sum(trial_us) / len(trial_us), "repeat_min_us": min(trial_us), "repeat_max_us": max(trial_us)} if trial_us else {})},
         "suffix_frac_by_suffix_len": buckets,
         "roofline": suffix_roof if dominant_is_suffix else prefix_roof,
@@ -514,14 +563,16 @@ def reference_protocol(ops, q, sk, sv, k, v, sweep, iters, with_nosharing):
     clean = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=dev)
     rows = {}
     for s in sweep:
-        g = _capture(lambda: ops.fused(s, torch.cuda.current_stream().cuda_stream))
+        g = ops.graph(s)
         rows[s] = {"hydragen_flushed": _stats(_timed_replays(g, iters, flush)),
                    "hydragen_flushed_clean": _stats(_timed_replays(g, iters, flush, clean)),
-                   "hydragen_back_to_back": _stats(_timed_replays(g, iters, None))}
-        del g
+                   "hydragen_back_to_back": _stats(_timed_replays(g, iters, None)),
+                   "two_stream_flushed_clean": _stats(_timed_replays(ops.graph(s, two_stream=True), iters, flush, clean)),
+                   "two_stream_back_to_back": _stats(_timed_replays(ops.graph(s, two_stream=True), iters, None))}
     del clean
     out = {
-        "protocol": "HIP-graph replay of one hyd_decode_attn_fused call, HIP events per replay, 512 MB flush between "
+        "protocol": "HIP-graph replay of the operator (one-call form unless --two-stream; two_stream_* = the two-stream form: it wins when every replay is "
+                    "timed alone and loses its gain to the two cross-queue edges when replays follow each other, DESIGN 4.8), HIP events per replay, 512 MB flush between "
                     "replays (and the same replays back to back); hydragen/benchmark_utils.py:82-170, scripts/microbenchmark.py:24-47. "
                     "The flush is a WRITE, as the reference's: on MI355X the 256 MB Infinity Cache then holds dirty lines "
                     "whose write-back is charged to the timed call (C5: +45 us); hydragen_flushed_clean reads a second "
@@ -534,6 +585,8 @@ def reference_protocol(ops, q, sk, sv, k, v, sweep, iters, with_nosharing):
     out["hydragen_flushed_mean_us"] = sum(r["hydragen_flushed"]["mean_us"] for r in rows.values()) / len(rows)
     out["hydragen_flushed_clean_mean_us"] = sum(r["hydragen_flushed_clean"]["mean_us"] for r in rows.values()) / len(rows)
     out["hydragen_back_to_back_mean_us"] = sum(r["hydragen_back_to_back"]["mean_us"] for r in rows.values()) / len(rows)
+    out["two_stream_back_to_back_mean_us"] = sum(r["two_stream_back_to_back"]["mean_us"] for r in rows.values()) / len(rows)
+    out["two_stream_flushed_clean_mean_us"] = sum(r["two_stream_flushed_clean"]["mean_us"] for r in rows.values()) / len(rows)
     if not with_nosharing:
         return out
     # no-sharing FlashAttention-equivalent (scripts/microbenchmark.py:91-127 go_baseline with --unique-seq-len): every
@@ -566,10 +619,8 @@ def reference_protocol(ops, q, sk, sv, k, v, sweep, iters, with_nosharing):
 
 
 def accuracy(ops, q, sk, sv, k, v, s):
-    """Measured error of the bf16 operator at this shape: 32 sequences x all heads against fp64 softmax attention over
-    the concatenated [prefix; suffix] keys of the same bf16 inputs (torch, on the GPU)."""
-    ops.fused(s, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    """Measured error of the bf16 operator at this shape, in both forms: 32 sequences x all heads against fp64 softmax
+    attention over the concatenated [prefix; suffix] keys of the same bf16 inputs (torch, on the GPU)."""
     B, _, Hq, D = q.shape
     g = Hq // sk.shape[2]
     idx = torch.linspace(0, B - 1, 32, device=q.device).long()
@@ -578,14 +629,26 @@ def accuracy(ops, q, sk, sv, k, v, s):
     vv = torch.cat([sv.expand(len(idx), -1, -1, -1), v[idx, :s]], 1).double().repeat_interleave(g, 2)
     sc = torch.einsum("bqhd,bkhd->bhqk", qs, kk) / math.sqrt(D)
     want = torch.einsum("bhqk,bkhd->bqhd", sc.softmax(-1), vv)
-    got = ops.out[idx].double()
-    diff = (got - want).abs()
+
+    def measure():
+        torch.cuda.synchronize()
+        got = ops.out[idx].double()
+        diff = (got - want).abs()
+        return {"max_abs_err": float(diff.max()), "mean_abs_err": float(diff.mean()),
+                "relative_l2": float((got - want).norm() / want.norm()),
+                "mean_rdiff": float((2 * diff / (got.abs() + want.abs() + 1e-8)).mean())}   # hydragen/utils.py:13-15
+
+    ops.out.zero_()
+    ops.two_stream_issue(s)
+    two = measure()
+    ops.out.zero_()
+    ops.fused(s, torch.cuda.current_stream().cuda_stream)
+    one = measure()
     return {
         "dtype": "bf16", "suffix_len": s, "sequences": int(len(idx)),
         "reference": "fp64 softmax attention over [prefix; suffix] on the same bf16 inputs",
-        "max_abs_err": float(diff.max()), "mean_abs_err": float(diff.mean()),
-        "relative_l2": float((got - want).norm() / want.norm()),
-        "mean_rdiff": float((2 * diff / (got.abs() + want.abs() + 1e-8)).mean()),   # hydragen/utils.py:13-15
+        **(two if ops.two_stream else one),
+        "one_call_form": one, "two_stream_form": two,
         "bf16_half_ulp_of_max_output": float(want.abs().max()) * 2.0 ** -9,
     }
 

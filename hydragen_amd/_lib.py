@@ -14,7 +14,7 @@ from pathlib import Path
 HYD_MAX_LEVELS = 8
 HYD_F16, HYD_BF16, HYD_F32 = 0, 1, 2
 HYD_LSE_BQH, HYD_LSE_BHQ = 0, 1
-HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE = 0, 1, 2
+HYD_PHASE_ALL, HYD_PHASE_SHARED, HYD_PHASE_UNIQUE, HYD_PHASE_UNIQUE_PARTIAL, HYD_PHASE_MERGE = 0, 1, 2, 3, 4
 
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libhydragen_hip.so"
 
@@ -68,6 +68,7 @@ class DecodeParams(C.Structure):
         ("suffix", SuffixParams), ("levels", Level * HYD_MAX_LEVELS),
         ("n_levels", C.c_int32), ("phase", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("shared_max_workgroups", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -105,6 +106,7 @@ EXPORTS = {
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hyd_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeParams)]),
     "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
+    "hyd_decode_two_stream_ok": (C.c_int, [C.POINTER(DecodeParams)]),
     "hyd_rope_append_decode": (C.c_int, [C.POINTER(RopeParams), C.c_void_p]),
     "hyd_ipc_get_handle": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hyd_ipc_open_handle": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -117,7 +119,7 @@ EXPORTS = {
 }
 
 _lib = None
-ABI_VERSION = 202  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
+ABI_VERSION = 300  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
 
 
 def lib_path() -> Path:

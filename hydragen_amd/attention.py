@@ -20,7 +20,8 @@ from torch import Tensor
 
 from . import _lib
 from . import flash as _flash
-from ._lib import HYD_F32, HYD_LSE_BQH, HYD_MAX_LEVELS, DecodeParams
+from ._lib import (HYD_F32, HYD_LSE_BQH, HYD_MAX_LEVELS, HYD_PHASE_ALL, HYD_PHASE_MERGE, HYD_PHASE_SHARED,
+                   HYD_PHASE_UNIQUE_PARTIAL, DecodeParams)
 from .flash import (
     _dtype_code, _lastdim_contig, _q_contig, _require_gpu, _stream, fill_suffix_params, prefix_attention,
 )
@@ -195,6 +196,73 @@ _PARAM_CACHE_MAX_BYTES = 256 << 20  # scratch held by cached entries
 _param_cache_bytes = 0
 
 
+# ---- two-stream form --------------------------------------------------------------------------------------------------
+# The prefix passes (matrix-core bound, ~no HBM traffic) and the suffix pass (HBM bound, ~no matrix-core work) do not
+# depend on each other; the reference issues them one after the other (attention.py:250-352).  Here the shared phase
+# CAN run on a side stream, limited to TWO_STREAM_PREFIX_CUS persistent workgroups, beside the unique phase on the
+# caller's stream, with a log-sum-exp combine behind the join (hyd_decode_params.phase, include/hydragen_hip.h).
+# Measured on MI355X at C2 (profiles/r03_overlap_graph.md, profiles/r03_two_stream.md): the passes do overlap -- a graph
+# replay timed ALONE drops from 220.6 to 200.5 us at suffix 64, 378 -> 361 at 128, 100.8 -> 90.3 at 16 -- but each of
+# the two cross-queue edges (fork, join) costs ~10 us whenever the queues are busy (~25 us for the pair issued
+# eagerly): replays that follow each other run at 220.7 vs 218.0 us per step, and the Llama-2-7B decode graph with the
+# form inside every layer at 26.96 vs 26.38 ms per step.  So the default is "off": the form is an option for callers
+# whose replays are isolated (the reference's own flush-between-iterations protocol), "auto" turns it on only while a
+# HIP graph is being captured and only for shapes whose prefix work is worth hiding.
+TWO_STREAM_PREFIX_CUS = 128
+_two_stream_mode = "off"
+_side_streams: dict = {}
+
+
+def set_two_stream(mode: str) -> str:
+    """"off" (default), "auto" (while capturing a HIP graph, for shapes with >= 4 GFLOP of prefix work) or "on"
+    (whenever the shapes have both parts).  Returns the previous mode."""
+    global _two_stream_mode
+    assert mode in ("auto", "on", "off"), mode
+    prev, _two_stream_mode = _two_stream_mode, mode
+    return prev
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _want_two_stream(q, k, shared_ks, shared_max_seq_lens, use_varlens, capturing: bool) -> bool:
+    if _two_stream_mode == "off" or not shared_ks or k.shape[1] == 0:
+        return False
+    if _two_stream_mode == "on":
+        return True
+    if not capturing or k.shape[1] < 16:  # a unique cache that short cannot hide a prefix pass
+        return False
+    b, nq, hq, d = q.shape
+    keys = sum(int(m) if uv else sk.shape[1] for sk, m, uv in zip(shared_ks, shared_max_seq_lens, use_varlens))
+    return 4.0 * b * nq * hq * d * keys >= 4.0e9  # prefix flops worth hiding (C2: 34e9, C1: 1e5)
+
+
+def _launch_decode(lib, p, two_stream: bool, stream: int):
+    """Issue the operator described by `p`: one call, or the three calls of the two-stream form."""
+    if not two_stream:
+        p.phase, p.shared_max_workgroups = HYD_PHASE_ALL, 0
+        _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    p.shared_max_workgroups = TWO_STREAM_PREFIX_CUS
+    side.wait_stream(main)
+    try:
+        p.phase = HYD_PHASE_SHARED
+        _lib.check(lib.hyd_decode_attn_fused(C.byref(p), side.cuda_stream))
+        p.phase = HYD_PHASE_UNIQUE_PARTIAL
+        _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
+    finally:
+        main.wait_stream(side)  # always join: a capture must not end with a dangling branch
+    p.phase = HYD_PHASE_MERGE
+    _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
+
+
 def _tensor_key(t):
     return None if t is None else (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
 
@@ -204,7 +272,9 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
     b, nq, hq, d = q.shape
     out = torch.empty_like(q)
     # no cache while capturing (the scratch belongs to the graph's private pool) or with a head-dim override (padded temporaries)
-    uncached = torch.cuda.is_current_stream_capturing() or _flash.current_softmax_scale() != 0.0
+    capturing = torch.cuda.is_current_stream_capturing()
+    uncached = capturing or _flash.current_softmax_scale() != 0.0
+    two_stream = _want_two_stream(q, k, shared_ks, shared_max_seq_lens, use_varlens, capturing)
     key = None
     stream = _stream()
     if not uncached:
@@ -215,7 +285,7 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
         if hit is not None:
             p = hit[0]
             p.suffix.out = out.data_ptr()
-            _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
+            _launch_decode(lib, p, two_stream, stream)
             return out
     p = DecodeParams()
     keep = [fill_suffix_params(p.suffix, q, k, v, seq_lens, out)]
@@ -234,7 +304,9 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
         keep.append(ws)
         p.workspace, p.workspace_bytes = ws.data_ptr(), ws_bytes
-    _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
+    if two_stream and not lib.hyd_decode_two_stream_ok(C.byref(p)):
+        two_stream = False
+    _launch_decode(lib, p, two_stream, stream)
     # cache only when every pointer in `p` refers to caller-owned memory or to tensors `keep` holds on to
     cacheable = key is not None and (seq_lens is None or seq_lens.dtype in (torch.int32, torch.int64)) and \
         all(x is None or x.is_contiguous() for x in shared_cu_seq_lens) and (seq_lens is None or seq_lens.is_contiguous())

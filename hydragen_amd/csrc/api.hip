@@ -178,15 +178,17 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
 
 // Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
 // `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
-int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s) {
+int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, int max_wgs, hipStream_t s) {
+    // max_wgs > 0: at most that many PERSISTENT workgroups walk the units (hyd_decode_params.shared_max_workgroups: the
+    // rest of the chip stays free for work on another stream); 0 = one workgroup per unit
 #ifdef HYD_ABLATION_BUILD
-    if (dev_switch("HYD_PREFIX_PL")) return launch_prefix_pl(a, dtype, D, causal, grid, s);  // round-1 kernel, A/B only
-    if (const int np = dev_switch("HYD_PREFIX_PERSIST")) grid = grid < np ? grid : np;
+    if (const int np = dev_switch("HYD_PREFIX_PERSIST")) max_wgs = np;
 #endif
+    if (max_wgs > 0 && grid > max_wgs) grid = max_wgs;
     return launch_prefix_w64(a, dtype, D, causal, grid, s);
 }
 
-int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s) {
+int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s, int max_wgs = 0) {
     PrefixArgs a;
     fill_prefix_args(p, pl, &a);
     const size_t rows = (size_t)p->B * p->nq * p->Hq;
@@ -195,7 +197,7 @@ int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hip
         a.lse = p->lse;
         a.out_f32 = 0;
         a.lse_layout = p->lse_layout;
-        int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
+        int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, max_wgs, s);
         return rc ? fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc) : HYD_OK;
     }
     const size_t esz = sizeof(float);
@@ -213,7 +215,7 @@ int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hip
     a.lse_layout = HYD_LSE_BQH;
     a.out_split_stride = (int64_t)(o_bytes / esz);
     a.lse_split_stride = (int64_t)(l_bytes / sizeof(float));
-    int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, s);
+    int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, max_wgs, s);
     if (rc) return fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc);
     if (!merge) return HYD_OK;
     CombineArgs c;
@@ -316,15 +318,6 @@ int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts
     if ((int64_t)p->kv_len * p->k_tok_stride * 2 >= (1ll << 31) || (int64_t)p->kv_len * p->v_tok_stride * 2 >= (1ll << 31))
         return fail(HYD_ERR_UNSUPPORTED, "unique K/V of one sequence spans >= 2 GiB (32-bit in-sequence offsets)");
     if (p->Hkv > 4 * 65535 || a.rows > 8 * 65535) return fail(HYD_ERR_UNSUPPORTED, "too many kv heads / query rows for the suffix grid");
-#ifdef HYD_ABLATION_BUILD
-    if (const int wgs = dev_switch("HYD_STREAM_WGS")) {  // the co-run kernel's streaming role alone, persistent, wgs workgroups
-        if (p->D == 128 && ((a.rows == 1 && a.g == 1) || dev_switch("HYD_STREAM_NBUF") == 100)) {
-            const int upi = dev_switch("HYD_CORUN_UPI") ? dev_switch("HYD_CORUN_UPI") : 8;
-            const int rc = launch_suffix_stream_dev(a, p->dtype, wgs, upi, dev_switch("HYD_STREAM_NBUF"), s);
-            return rc ? fail(HYD_ERR_LAUNCH, "stream kernel launch failed: hip error %d", rc) : HYD_OK;
-        }
-    }
-#endif
     int rc = launch_suffix(a, p->dtype, p->D, s);
     return rc ? fail(HYD_ERR_LAUNCH, "suffix kernel launch failed: hip error %d", rc) : HYD_OK;
 }
@@ -389,22 +382,10 @@ int run_level_small(const hyd_prefix_params& pp, const PrefixPlan& pl, void* out
 // each level may cut its keys into at most kMaxCombine / n_levels slices (>= 8 with HYD_MAX_LEVELS = 8).
 int level_split_cap(int n_levels) { return n_levels > 0 ? kMaxCombine / n_levels : kMaxSplits; }
 
-// Co-run (corun_attn.hip): one shared level, one query row per (sequence, kv head), the 128-row prefix instantiation.
-// Scratch: two fp32 partials (out + lse each) and the 1 KiB queue block.
-size_t corun_ws_bytes(size_t rows, int D) {
-    return 2 * (align_up(rows * D * 4, 256) + align_up(rows * 4, 256)) + kCorunQueueBytes;
-}
-
-bool corun_shapes_ok(const hyd_decode_params* p, const hyd_prefix_params& pp, const PrefixPlan& pl) {
-    const hyd_suffix_params& s = p->suffix;
-    return p->n_levels == 1 && s.D == 128 && s.nq == 1 && s.Hq == s.Hkv && s.kv_len > 0 && !pp.cu_seqlens_k && pl.nsplit == 1 &&
-           pl.wg_rows == 128 && (int64_t)s.kv_len * (s.k_tok_stride > s.v_tok_stride ? s.k_tok_stride : s.v_tok_stride) * 2 < ((int64_t)1 << 31);
-}
-
-// shapes-only policy: when the one-launch co-run form is used instead of prefix pass -> suffix pass
-bool corun_wanted(const hyd_decode_params* p, const hyd_prefix_params& pp, const PrefixPlan& pl) {
-    if (p->phase != HYD_PHASE_ALL || !corun_shapes_ok(p, pp, pl)) return false;
-    return dev_switch("HYD_CORUN") != 0;
+// Scratch of the two-stream form: the unique pass's partial, a 16-bit [B, nq, Hq, D] + its fp32 LSE [B, nq, Hq].
+size_t unique_partial_bytes(const hyd_suffix_params& sp) {
+    const size_t rows = (size_t)sp.B * sp.nq * sp.Hq;
+    return align_up(rows * sp.D * 2, 256) + align_up(rows * 4, 256);
 }
 
 // per-level workspace: nsplit == 1 -> one dtype slice + lse; nsplit > 1 -> fp32 slices (prefix_ws_bytes)
@@ -610,11 +591,9 @@ size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {
         PrefixPlan pl;
         if (plan_prefix(&pp, &pl, level_split_cap(p->n_levels))) return 0;
         total += level_ws_bytes(pp, pl);
-        if (i == 0 && corun_shapes_ok(p, pp, pl)) {  // either form may be chosen per call (phase): size for both
-            const size_t c = corun_ws_bytes((size_t)p->suffix.B * p->suffix.nq * p->suffix.Hq, p->suffix.D);
-            if (c > total) total = c;
-        }
     }
+    // the unique pass's own partial (HYD_PHASE_UNIQUE_PARTIAL / HYD_PHASE_MERGE: the two-stream form)
+    if (p->n_levels > 0 && p->suffix.kv_len > 0) total += unique_partial_bytes(p->suffix);
     return total;
 }
 
@@ -629,6 +608,7 @@ size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32
     p.suffix.Hq = Hq;
     p.suffix.Hkv = Hkv;
     p.suffix.D = D;
+    p.suffix.kv_len = 1;  // a decode step has unique keys: size the unique partial of the two-stream form as well
     p.n_levels = n_levels;
     for (int i = 0; i < n_levels; ++i) {
         p.levels[i].sb = level_sb[i];
@@ -640,15 +620,21 @@ size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32
 int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
     if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
     if (p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return fail(HYD_ERR_BAD_ARG, "n_levels %d", p->n_levels);
-    if (p->phase != HYD_PHASE_ALL && p->phase != HYD_PHASE_SHARED && p->phase != HYD_PHASE_UNIQUE)
-        return fail(HYD_ERR_BAD_ARG, "phase %d", p->phase);
+    if (p->phase < HYD_PHASE_ALL || p->phase > HYD_PHASE_MERGE) return fail(HYD_ERR_BAD_ARG, "phase %d", p->phase);
+    if (p->shared_max_workgroups < 0) return fail(HYD_ERR_BAD_ARG, "shared_max_workgroups %d", p->shared_max_workgroups);
     const hyd_suffix_params& sp = p->suffix;
     int rc = check_suffix(&sp, true);
     if (rc) return rc;
     if (p->n_levels == 0 && sp.kv_len == 0) return fail(HYD_ERR_BAD_ARG, "no shared levels and no unique keys");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t rows = (size_t)sp.B * sp.nq * sp.Hq;
-    const bool do_shared = p->phase != HYD_PHASE_UNIQUE, do_unique = p->phase != HYD_PHASE_SHARED;
+    const bool do_shared = p->phase == HYD_PHASE_ALL || p->phase == HYD_PHASE_SHARED;
+    const bool do_unique = p->phase == HYD_PHASE_ALL || p->phase == HYD_PHASE_UNIQUE;
+    const bool two_stream = p->phase == HYD_PHASE_UNIQUE_PARTIAL || p->phase == HYD_PHASE_MERGE;
+    // The two-stream form needs both a shared and a unique part; without one of them the in-order phases already are
+    // the whole operator (the caller asks hyd_decode_two_stream_ok first).
+    if (two_stream && (p->n_levels == 0 || sp.kv_len == 0))
+        return fail(HYD_ERR_UNSUPPORTED, "two-stream phases need at least one shared level and unique keys");
 
     if (decode_is_prefix_only(p)) {
         if (!do_shared) return HYD_OK;  // nothing left for the unique phase
@@ -662,7 +648,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         pp.lse = nullptr;
         pp.workspace = p->workspace;
         pp.workspace_bytes = p->workspace_bytes;
-        return run_prefix(&pp, pl, true, s);
+        return run_prefix(&pp, pl, true, s, p->shared_max_workgroups);
     }
 
     // ---- plan and validate everything before the first launch ----------------------------------------------
@@ -682,50 +668,11 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         need += bytes[i];
         n_parts += (pls[i].nsplit == 1 || small[i]) ? 1 : pls[i].nsplit;
     }
-    if (n_parts > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "%d partials (more than %d)", n_parts, kMaxCombine);
+    if (n_parts + (two_stream ? 1 : 0) > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "%d partials (more than %d)", n_parts, kMaxCombine);
+    const size_t levels_bytes = need;
+    if (two_stream) need += unique_partial_bytes(sp);
     if (need > 0 && (!p->workspace || p->workspace_bytes < need))
         return fail(HYD_ERR_WORKSPACE, "decode needs %zu workspace bytes, got %zu", need, p->workspace_bytes);
-
-    if (!small[0] && corun_wanted(p, pps[0], pls[0])) {
-        const size_t cneed = corun_ws_bytes(rows, sp.D);
-        if (!p->workspace || p->workspace_bytes < cneed)
-            return fail(HYD_ERR_WORKSPACE, "decode (co-run) needs %zu workspace bytes, got %zu", cneed, p->workspace_bytes);
-        char* w = static_cast<char*>(p->workspace);
-        const size_t ob = align_up(rows * sp.D * 4, 256), lb = align_up(rows * 4, 256);
-        float* po = reinterpret_cast<float*>(w);
-        float* pl_ = reinterpret_cast<float*>(w + ob);
-        float* so = reinterpret_cast<float*>(w + ob + lb);
-        float* sl = reinterpret_cast<float*>(w + 2 * ob + lb);
-        unsigned* queue = reinterpret_cast<unsigned*>(w + 2 * ob + 2 * lb);
-        PrefixArgs pa;
-        fill_prefix_args(&pps[0], pls[0], &pa);
-        pa.out = po;
-        pa.lse = pl_;
-        pa.out_f32 = 1;
-        pa.lse_layout = HYD_LSE_BQH;
-        SuffixArgs sa;
-        fill_suffix_args(&sp, &sa);
-        sa.out = so;
-        sa.lse = sl;
-        if (!corun_eligible(pa, sa, sp.D, false)) return fail(HYD_ERR_UNSUPPORTED, "co-run form chosen for a shape it does not cover");
-        const int np = dev_switch("HYD_CORUN_NP") ? dev_switch("HYD_CORUN_NP") : 2;
-        const int upi = dev_switch("HYD_CORUN_UPI") ? dev_switch("HYD_CORUN_UPI") : 8;
-        rc = launch_corun(pa, sa, sp.dtype, queue, kNumCU, np, upi, s);
-        if (rc) return fail(HYD_ERR_LAUNCH, "co-run kernel launch failed: hip error %d", rc);
-        CombineArgs c;
-        memset(&c, 0, sizeof(c));
-        c.outs[0] = po; c.lses[0] = pl_;
-        c.outs[1] = so; c.lses[1] = sl;
-        c.n = 2;
-        c.rows = (int64_t)rows;
-        c.D = sp.D;
-        c.dtype_in = HYD_F32;
-        c.dtype_out = sp.dtype;
-        c.out = sp.out;
-        c.lse_layout = HYD_LSE_BQH;
-        rc = launch_combine(c, s);
-        return rc ? fail(HYD_ERR_LAUNCH, "combine kernel launch failed: hip error %d", rc) : HYD_OK;
-    }
 
     hyd_partial parts[HYD_MAX_LEVELS];
     char* ws = static_cast<char*>(p->workspace);
@@ -749,10 +696,46 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         }
         if (do_shared) {
             if (small[i]) rc = run_level_small(pp, pl, const_cast<void*>(parts[i].out), const_cast<float*>(parts[i].lse), s);
-            else rc = run_prefix(&pp, pl, /*merge=*/false, s);
+            else rc = run_prefix(&pp, pl, /*merge=*/false, s, p->shared_max_workgroups);
             if (rc) return rc;
         }
         ws += bytes[i];
+    }
+    if (two_stream) {
+        // the unique pass's partial lives behind the levels' regions
+        char* up = static_cast<char*>(p->workspace) + levels_bytes;
+        void* u_out = up;
+        float* u_lse = reinterpret_cast<float*>(up + align_up(rows * sp.D * 2, 256));
+        if (p->phase == HYD_PHASE_UNIQUE_PARTIAL) {
+            hyd_suffix_params su = sp;
+            su.out = u_out;
+            su.lse = u_lse;
+            return run_suffix(&su, nullptr, 0, s);
+        }
+        CombineArgs c;  // HYD_PHASE_MERGE: every level's partial(s) + the unique partial -> out
+        memset(&c, 0, sizeof(c));
+        int n = 0;
+        for (int i = 0; i < p->n_levels; ++i) {
+            const size_t esz = parts[i].is_f32 ? 4 : 2;
+            const size_t ostride = parts[i].count > 1 ? align_up(rows * sp.D * esz, 256) : rows * sp.D * esz;
+            const size_t lstride = parts[i].count > 1 ? align_up(rows * 4, 256) : rows * 4;
+            for (int j = 0; j < parts[i].count; ++j, ++n) {
+                c.outs[n] = static_cast<const char*>(parts[i].out) + (size_t)j * ostride;
+                c.lses[n] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(parts[i].lse) + (size_t)j * lstride);
+                if (parts[i].is_f32) c.f32_mask |= 1ull << n;
+            }
+        }
+        c.outs[n] = u_out;
+        c.lses[n] = u_lse;
+        c.n = n + 1;
+        c.rows = (int64_t)rows;
+        c.D = sp.D;
+        c.dtype_in = c.f32_mask ? HYD_MIXED : sp.dtype;
+        c.dtype_out = sp.dtype;
+        c.out = sp.out;
+        c.lse_layout = HYD_LSE_BQH;
+        rc = launch_combine(c, s);
+        return rc ? fail(HYD_ERR_LAUNCH, "combine kernel launch failed: hip error %d", rc) : HYD_OK;
     }
     if (!do_unique) return HYD_OK;
     if (sp.kv_len == 0) {
@@ -763,6 +746,10 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         return run_suffix(&s0, parts, p->n_levels, s);
     }
     return run_suffix(&sp, parts, p->n_levels, s);
+}
+
+int hyd_decode_two_stream_ok(const hyd_decode_params* p) {
+    return p && p->n_levels > 0 && p->n_levels <= HYD_MAX_LEVELS && p->suffix.kv_len > 0 && !decode_is_prefix_only(p) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -14,14 +14,13 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-SOURCES = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "corun_attn.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
+SOURCES = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
 HEADERS = sorted(h.name for h in HERE.glob("*.h")) + ["../../include/hydragen_hip.h"]
 LIB = HERE / "libhydragen_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Werror", "-Wno-unused-function"]
-if os.environ.get("HYD_ABLATION_BUILD"):  # development only: A/B switches + the superseded round-1 prefix kernel
+if os.environ.get("HYD_ABLATION_BUILD"):  # development only: A/B switches, timing-ablation kernel variants
     FLAGS.append("-DHYD_ABLATION_BUILD")
-    SOURCES.append("prefix_attn_pl.hip")
 
 
 def _stale(target: Path, deps) -> bool:

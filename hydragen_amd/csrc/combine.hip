@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void combine_scalar_kernel(const CombineArgs a
         for (int i = 0; i < a.n; ++i) {
             const float w = __expf(a.lses[i][row] - Ms);
             den += w;
-            num = __builtin_fmaf(w, load_as_f32(a.outs[i], idx, a.dtype_in), num);
+            const int dt = a.dtype_in == HYD_MIXED ? (((a.f32_mask >> i) & 1) ? HYD_F32 : a.dtype_out) : a.dtype_in;
+            num = __builtin_fmaf(w, load_as_f32(a.outs[i], idx, dt), num);
         }
         store_from_f32(a.out, idx, a.dtype_out, den > 0.f ? num / den : 0.f);
         if (a.out_lse && idx % a.D == 0) a.out_lse[lse_out_index(a, row)] = den > 0.f ? M + __logf(den) : -INFINITY;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void combine_vec_kernel(const CombineArgs a) {
             const float w = __expf(a.lses[i][row] - Ms);
             den += w;
             float x[8];
-            if (DT_IN == HYD_F32) {
+            if (DT_IN == HYD_F32 || (DT_IN == HYD_MIXED && ((a.f32_mask >> i) & 1))) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.outs[i]) + e0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.outs[i]) + e0 + 4);
 #pragma unroll
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void combine_vec_kernel(const CombineArgs a) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.outs[i]) + e0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (DT_IN == HYD_BF16) {
+                    if (DT_IN == HYD_BF16 || (DT_IN == HYD_MIXED && DT_OUT == HYD_BF16)) {
                         x[2 * j] = Traits<BF16>::lo(v[j]);
                         x[2 * j + 1] = Traits<BF16>::hi(v[j]);
                     } else {
@@ -129,6 +130,8 @@ int launch_combine(const CombineArgs& a, hipStream_t s) {
     HYD_CMB(HYD_F32, HYD_F32)
     HYD_CMB(HYD_F32, HYD_F16)
     HYD_CMB(HYD_F32, HYD_BF16)
+    HYD_CMB(HYD_MIXED, HYD_F16)
+    HYD_CMB(HYD_MIXED, HYD_BF16)
 #undef HYD_CMB
     hipLaunchKernelGGL(combine_scalar_kernel, dim3(grid), dim3(256), 0, s, a);
     return (int)hipGetLastError();

@@ -4,7 +4,8 @@
 
 namespace hyd {
 
-constexpr int kMaxCombine = 64;  // partials one combine launch / one suffix epilogue can merge
+constexpr int kMaxCombine = 64;  // (f32_mask of CombineArgs is 64 bits wide)
+constexpr int HYD_MIXED = 3;     // CombineArgs.dtype_in only: the partials are a mix of fp32 and the 16-bit output dtype  // partials one combine launch / one suffix epilogue can merge
 
 struct PrefixArgs {
     const void* q;
@@ -60,7 +61,8 @@ struct CombineArgs {
     void* out;
     float* out_lse;
     int64_t rows;
-    int32_t n, D, dtype_in, dtype_out;  // dtype_in may be HYD_F32 with a 16-bit dtype_out
+    int32_t n, D, dtype_in, dtype_out;  // dtype_in may be HYD_F32 with a 16-bit dtype_out; HYD_MIXED: per-partial, f32_mask
+    uint64_t f32_mask;                  // dtype_in == HYD_MIXED: bit i set = partial i is fp32, else it has dtype_out
     // optional BHQ re-layout of out_lse: row = tok*Hq + h -> ((tok / qpg)*Hq + h)*qpg + tok % qpg
     int32_t lse_layout, Hq, qpg;
     int32_t scalar_only;  // force the element-wise kernel (unaligned tensors)
@@ -85,20 +87,12 @@ struct RopeArgs {
 };
 
 // launchers (defined next to the kernels); return hipError_t as int
-int launch_prefix_pl(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);   // ablation builds only
 int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
 int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape);
 int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 int launch_combine(const CombineArgs& a, hipStream_t s);
-// co-run kernel (corun_attn.hip): prefix pass and suffix pass side by side in one launch; both write fp32 partials
-constexpr size_t kCorunQueueBytes = 1024;
-bool corun_eligible(const PrefixArgs& pa, const SuffixArgs& sa, int D, bool causal);
-int launch_corun(const PrefixArgs& pa, const SuffixArgs& sa, int dtype, unsigned* queue, int grid, int np_of8, int upi, hipStream_t s);
-bool gqa_stream_eligible(const SuffixArgs& a, int D);
-int launch_suffix_gqa_stream(const SuffixArgs& a, int dtype, unsigned* queue, int waves, int upi, hipStream_t s);
-int launch_suffix_stream_dev(const SuffixArgs& sa, int dtype, int grid, int upi, int nbuf, hipStream_t s);  // ablation builds only
 size_t allreduce_block_bytes(int world, size_t max_bytes);
 int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, void* out, int64_t count, int dtype,
                      int rank, int world, size_t max_bytes, int timeout_log2_polls, hipStream_t s);

@@ -1,5 +1,5 @@
 #pragma once
-// Prefix pass (unit body, shared by prefix_attn_w64.hip and corun_attn.hip): batched-query attention of all queries of a group against the group's single shared K/V, on the
+// Prefix pass (unit body; the kernel and its launcher are in prefix_attn_w64.hip): batched-query attention of all queries of a group against the group's single shared K/V, on the
 // gfx950 matrix cores.  Replaces flash-attn's _flash_attn_forward / _flash_attn_varlen_forward as called from
 // /root/reference/hydragen/flash.py:284-351 and hydragen/attention.py:270,313,344.
 //
@@ -876,20 +876,20 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     const int kwave = kbeg + kg * 64;  // first key of this wave's half of tile 0
     // Iterations i = -1 .. NB; the pipeline's fill (i = -1: QK(0) only; i = 0: QK(1) + softmax(0)) and drain
     // (i = NB-1: softmax + PV, no QK; i = NB: PV(NB-1) only) run their own, shorter instantiations of the iteration.
-    // Cold start: only what the first iteration needs is waited for (Q, K blocks 0 and 1); K block 2 and V block 0 are
-    // issued behind that wait and land during iterations -1 / 0.
+    // Cold start: the first iteration (QK(0) alone) needs the Q fragments and K block 0 only.  K blocks 1, 2 and V
+    // block 0 are issued behind them and the wait leaves those three blocks in flight (vector-memory operations retire
+    // in issue order): the prologue is a bandwidth burst of every workgroup of the launch at once (~11 B / cycle / CU),
+    // so every KiB not waited for is ~90 cycles.  The counted wait that ends iteration -1 covers them; that iteration
+    // therefore does not prefetch block 1's first fragments in its tail (FL_FIRST), they are read behind its barrier.
     if (NB > 0) {
         dma_block(0, false);
         dma_block(1, false);
-    }
-    // Wait for the Q fragments (asm loads: hipcc does not count them) and the first two K blocks; every consumer is
-    // a volatile asm statement behind this one.
-    stampk(1);
-    dma_wait_w<0>();
-    if (NB > 0) {
-        dma_block(2, false);  // covered by the counted wait that ends iteration -1
+        dma_block(2, false);
         dma_block(0, true);
     }
+    stampk(1);
+    if (NB > 0) dma_wait_w<3 * NLB>();
+    else dma_wait_w<0>();
     __syncthreads();
     stampk(2);
     if (NB > 0) {
@@ -899,7 +899,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         //   reads  K block ii+1 -> slot R, V block ii-1 -> slot (R+2)&3;  next iteration: (R+1)&3, (R+3)&3
         //   writes K block ii+4 -> slot (R+3)&3, V block ii+2 -> slot (R+1)&3.      ii odd <=> R even.
         // FL: 1 QK | 2 softmax | 4 PV | 8 masking possible | 16 / 32: the next iteration has QK / PV (fragment prefetch)
-        constexpr int FL_FULL = 7 + 8 + 16 + 32, FL_FIRST = 1 + 16, FL_SECOND = 1 + 2 + 8 + 16 + 32,
+        constexpr int FL_FULL = 7 + 8 + 16 + 32, FL_FIRST = 1, FL_SECOND = 1 + 2 + 8 + 16 + 32,
                       FL_PENULT = 2 + 4 + 8 + 32, FL_LAST = 4;
         // Scalars that advance by one 32-key block per iteration (kept incremental: the loop is issue-bound and every
         // scalar instruction between two MFMAs costs a slot): byte offset of K block ii+4 and of V block ii+2 inside
@@ -924,6 +924,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     }
         int i0 = -1;
         HYD_IT(0, FL_FIRST, S0, S1, P1, P0)
+#pragma unroll
+        for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, slot_k(1));  // K block 1 is visible only now (cold start, above)
         HYD_IT(1, FL_SECOND, S1, S0, P0, P1)
         for (;;) {
             if (i0 + 4 >= NB) {

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hip/hip_ext.h>
+
 #include "suffix_common.h"
 
 namespace hyd {
@@ -325,6 +327,13 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 4>), grid, dim3(256), 0, s, a);
     } else {
         dim3 grid(a.B, (a.Hkv + 3) / 4, row_chunks);
+#ifdef HYD_ABLATION_BUILD
+        // timing probe only (results race with the prefix pass): launch without the in-queue barrier
+        if (const char* e = getenv("HYD_ANYORDER"); e && atoi(e)) {
+            hipExtLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, a);
+            return (int)hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();

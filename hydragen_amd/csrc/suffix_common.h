@@ -1,5 +1,4 @@
-// Device-side pieces shared by the suffix-pass kernels (suffix_attn.hip) and the co-run kernel's streaming role
-// (suffix_stream.h): 16-bit widening, uniform pointers, online-softmax state merges, the output-row epilogue.
+// Device-side pieces of the suffix-pass kernels (suffix_attn.hip): 16-bit widening, uniform pointers, online-softmax state merges, the output-row epilogue.
 #pragma once
 #include "hyd_kernels.h"
 

@@ -1,4 +1,4 @@
-// Device-side pieces shared by the matrix-core suffix kernels (suffix_attn_gqa.hip, suffix_gqa_stream.h): asm MFMAs,
+// Device-side pieces of the matrix-core suffix kernel (suffix_attn_gqa.hip): asm MFMAs,
 // transposing LDS reads, buffer resources, LDS-DMA, the asm-owned K register sets a[0:63], cross-lane reductions.
 #pragma once
 #include <type_traits>

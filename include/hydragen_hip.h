@@ -44,7 +44,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
 #define HYD_API __attribute__((visibility("default")))
 
-#define HYD_VERSION 202 /* 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
+#define HYD_VERSION 300 /* 0.3.0: two-stream phases + hyd_decode_params.shared_max_workgroups, hyd_decode_two_stream_ok; 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
 #define HYD_MAX_LEVELS 8
 
 enum {
@@ -159,8 +159,18 @@ typedef struct hyd_level {
  * per-level prefix passes (they read q and the shared caches and fill the workspace); UNIQUE runs only
  * the suffix pass + merge and expects the workspace as a SHARED call with the same parameters left it.
  * The two halves touch disjoint inputs (the unique K/V and seq_lens are read by UNIQUE only), so a
- * caller may run SHARED on one stream while this step's k/v are still being appended on another. */
-enum { HYD_PHASE_ALL = 0, HYD_PHASE_SHARED = 1, HYD_PHASE_UNIQUE = 2 };
+ * caller may run SHARED on one stream while this step's k/v are still being appended on another.
+ *
+ * Two-stream form (the reference issues the two passes one after the other, attention.py:250-352; they do not
+ * depend on each other, the prefix pass is matrix-core bound and the suffix pass HBM bound):
+ *   stream A: SHARED            (with shared_max_workgroups > 0 the prefix pass keeps to that many CUs)
+ *   stream B: UNIQUE_PARTIAL    suffix pass alone; its normalised partial + LSE go to the workspace
+ *   join, then MERGE            log-sum-exp combine of every partial into `out` (attention.py:21-43)
+ * with the same parameters (and workspace) in all three calls.  The caller owns the streams and the
+ * fork / join (events, or the edges of a captured graph); hyd_decode_two_stream_ok() says whether the
+ * shapes have both parts.  Results equal the one-call form up to one extra rounding of the unique partial
+ * to the 16-bit dtype. */
+enum { HYD_PHASE_ALL = 0, HYD_PHASE_SHARED = 1, HYD_PHASE_UNIQUE = 2, HYD_PHASE_UNIQUE_PARTIAL = 3, HYD_PHASE_MERGE = 4 };
 
 typedef struct hyd_decode_params {
     hyd_suffix_params suffix;    /* q, unique k/v, seq_lens, out; n_partials/partials ignored */
@@ -169,10 +179,15 @@ typedef struct hyd_decode_params {
     int32_t phase;               /* HYD_PHASE_*                                               */
     void* workspace;             /* >= hyd_decode_workspace_bytes()                           */
     size_t workspace_bytes;
+    int32_t shared_max_workgroups; /* 0 = one workgroup per unit of a prefix pass (the whole chip); > 0: at most
+                                    * that many persistent workgroups, one per CU, walk the units           */
+    int32_t reserved_;
 } hyd_decode_params;
 
 HYD_API size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);
 HYD_API int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
+/* 1 when the shapes have both a shared and a unique part (the two-stream phases apply), else 0. */
+HYD_API int hyd_decode_two_stream_ok(const hyd_decode_params* p);
 
 /* Upper bound helper mirroring SURVEY 8b's `hyd_workspace_bytes(shape...)`: bytes that
  * hyd_decode_attn_fused needs for n_levels uniform levels of the given shapes. */

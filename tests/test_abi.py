@@ -20,7 +20,7 @@ def test_exports_match_header():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.hyd_version() == 202 == _lib.ABI_VERSION
+    assert lib.hyd_version() == 300 == _lib.ABI_VERSION
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
@@ -160,11 +160,12 @@ def test_deep_hierarchy_partials_fit_the_merge_budget():
     B, Hq, D, n = 64, 8, 128, 16384
     rows = B * Hq
     per_slice = rows * D * 4 + rows * 4
+    unique = rows * D * 2 + rows * 4  # the unique pass's own 16-bit partial + LSE (two-stream form), behind the levels
     d = _decode(B, Hq, 1, D, [(1, n), (2, n), (4, n)])
     ws = lib.hyd_decode_workspace_bytes(C.byref(d))
-    assert 0 < ws <= 3 * (64 // 3) * per_slice
+    assert unique < ws <= 3 * (64 // 3) * per_slice + unique
     one = _decode(B, Hq, 1, D, [(1, n)])
-    assert lib.hyd_decode_workspace_bytes(C.byref(one)) == 32 * per_slice  # a single level keeps its 32 slices
+    assert lib.hyd_decode_workspace_bytes(C.byref(one)) == 32 * per_slice + unique  # a single level keeps its 32 slices
 
 
 def test_phase_argument_is_validated():

@@ -69,3 +69,79 @@ def test_combine_lse_vs_reference_grid():
         from oracle import hydragen_oracle as O
         want = O.combine_lse([o.float().cpu().numpy() for o in outs], list(z["n3_lses"]))
         assert np.abs(r - want).max() <= ATOL[dt]
+
+
+@pytest.mark.parametrize("name,kw", CASES, ids=[c[0] for c in CASES])
+def test_two_stream_form_vs_golden(name, kw):
+    """The two-stream form (shared phase on a side stream with persistent prefix workgroups, unique phase beside it,
+    log-sum-exp combine after the join; attention.py:250-352 issues the same passes in order) against the same fixtures
+    and the same tolerances as the one-call form."""
+    from hydragen_amd import attention as A
+
+    case = make_case(**kw)
+    g = load_golden(name)
+    d = case_to_device(case)
+    prev = A.set_two_stream("on")
+    cus = A.TWO_STREAM_PREFIX_CUS
+    try:
+        for A.TWO_STREAM_PREFIX_CUS in (cus, 3):  # 3: far fewer workgroups than units -> every workgroup walks several
+            out = A.hydragen_attention(**d)
+            torch.cuda.synchronize()
+            o = out.float().cpu().numpy()
+            assert_close(o, g["out_exact"], case["dtype"], f"{name} two-stream vs float64 oracle")
+            if "out_ref" in g:
+                assert_close(o, g["out_ref"], case["dtype"], f"{name} two-stream vs reference python")
+    finally:
+        A.TWO_STREAM_PREFIX_CUS = cus
+        A.set_two_stream(prev)
+
+
+def test_two_stream_form_is_chosen_and_correct_under_graph_capture():
+    """Mode 'auto' picks the two-stream form only while a HIP graph is captured and only for shapes with enough prefix work;
+    the replayed graph must give the one-call result (up to the unique partial's extra rounding) on every replay, also
+    after the inputs changed in place."""
+    from hydragen_amd import attention as A
+
+    torch.manual_seed(5)
+    B, P, S, H, D = 256, 1024, 32, 32, 128   # 4 * B * H * D * P = 17e9 flops: above the 'auto' threshold
+    q = torch.randn(B, 1, H, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    sk = torch.randn(1, P, H, D, device="cuda", dtype=torch.bfloat16)
+    sv = torch.randn_like(sk)
+    sl = torch.randint(1, S + 1, (B,), device="cuda", dtype=torch.int32)
+    assert not A._want_two_stream(q, k, [sk], [None], [False], capturing=True)  # default mode: off
+    prev = A.set_two_stream("auto")
+    assert A._want_two_stream(q, k, [sk], [None], [False], capturing=True)
+    assert not A._want_two_stream(q, k, [sk], [None], [False], capturing=False)
+    assert not A._want_two_stream(q[:2], k[:2], [sk], [None], [False], capturing=True)
+    calls = []
+    orig = A._launch_decode
+    A._launch_decode = lambda lib, p, two, st: (calls.append(two), orig(lib, p, two, st))[1]
+    try:
+        want = A.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            A.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = A.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
+    finally:
+        A._launch_decode = orig
+        A.set_two_stream(prev)
+    assert calls == [False, False, True]
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert (out.float() - want.float()).abs().max().item() <= 2 * ATOL["bf16"] / 16  # one extra bf16 rounding of a 3 % share
+    q.copy_(torch.randn_like(q))
+    sl.copy_(torch.randint(1, S + 1, (B,), device="cuda", dtype=torch.int32))
+    g.replay()
+    torch.cuda.synchronize()
+    want2 = A.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
+    torch.cuda.synchronize()
+    assert (out.float() - want2.float()).abs().max().item() <= 2 * ATOL["bf16"] / 16

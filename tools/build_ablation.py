@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool: build an ablation library (HYD_ABLATION_BUILD: A/B environment switches, timing-ablation kernel
-variants, the superseded round-1 prefix kernel) into build_probe/libhydragen_abl.so without touching the product
+variants) into build_probe/libhydragen_abl.so without touching the product
 objects.  Use it with HYDRAGEN_HIP_LIB=build_probe/libhydragen_abl.so."""
 import subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
@@ -9,7 +9,7 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 src, out = REPO / "hydragen_amd" / "csrc", REPO / "build_probe"
 out.mkdir(exist_ok=True)
-srcs = ["api.hip", "prefix_attn_w64.hip", "prefix_attn_pl.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "corun_attn.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
+srcs = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DHYD_ABLATION_BUILD", "-Wno-unused-function"]
 
 
