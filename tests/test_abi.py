@@ -121,8 +121,9 @@ def test_decode_workspace_accounting():
     sb = (C.c_int32 * 2)(1, 32)
     ln = (C.c_int32 * 2)(1024, 64)
     rows = 1024 * 32
-    # C4: two levels, both fill the chip -> one bf16 slice + one fp32 LSE vector per level
-    want = 2 * (rows * 128 * 2 + rows * 4)
+    # C4: two levels, both fill the chip -> one bf16 slice + one fp32 LSE vector per level, + the same for the unique
+    # pass's own partial (two-stream form)
+    want = 3 * (rows * 128 * 2 + rows * 4)
     assert lib.hyd_workspace_bytes(1024, 1, 32, 32, 128, 2, sb, ln) == want
     d = DecodeParams()
     d.suffix.dtype, d.suffix.B, d.suffix.nq, d.suffix.Hq, d.suffix.Hkv, d.suffix.D = 1, 1024, 1, 32, 32, 128
