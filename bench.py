@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-protocol", action="store_true", help="skip the graph + flush reference-protocol sweep")
     ap.add_argument("--no-model", action="store_true", help="skip the Llama-2-7B decode tokens/s leg")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--no-paper-sweep", action="store_true", help="skip the reference microbenchmark's own sweep corners (8 q / 1 kv heads)")
     ap.add_argument("--two-stream", action="store_true",
                     help="steps replay the two-stream form of the operator instead of the one-call form (A/B; DESIGN 4.8)")
     ap.add_argument("--trials", type=int, default=3, help="repetitions of the K-step schedule after the headline region (spread)")
@@ -133,6 +134,9 @@ class Ops:
             # the two-stream form's shared phase keeps to half of the chip (persistent prefix workgroups)
             ps["shared_side"] = DecodeParams.from_buffer_copy(ps[HYD_PHASE_SHARED])
             ps["shared_side"].shared_max_workgroups = attention.TWO_STREAM_PREFIX_CUS
+            ps["f32_partials"] = DecodeParams.from_buffer_copy(ps[HYD_PHASE_ALL])
+            ps["f32_partials"].f32_partials = 1
+            ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(ps["f32_partials"])))
             ws_bytes = max(ws_bytes, self.lib.hyd_decode_workspace_bytes(C.byref(ps[HYD_PHASE_ALL])))
             self.params[s] = ps
             self.keep.append(sl)
@@ -413,8 +417,12 @@ def main():
             res["nosharing_speedup"] = ns
     if rank == 0 and not args.no_accuracy:
         res["accuracy"] = accuracy(ops, q, sk, sv, k, v, S // 2)
+    if solo and not args.no_paper_sweep:
+        ops = q = k = v = sk = sv = None  # 2.3 GB of C2 tensors and the captured graphs: free them for the sweep's 18 GB
+        torch.cuda.empty_cache()
+        res["paper_sweep"] = _guarded(lambda: paper_sweep(max(4, args.protocol_iters // 3)), 120.0, res, rank, key="paper_sweep")
     if solo and not args.no_model:
-        del ops
+        ops = None
         torch.cuda.empty_cache()
         try:
             res["model_decode"] = model_decode(B, P, args.model_new_tokens)
@@ -618,6 +626,42 @@ def reference_protocol(ops, q, sk, sv, k, v, sweep, iters, with_nosharing):
     return out
 
 
+def paper_sweep(iters):
+    """The reference's own attention microbenchmark (scripts/microbenchmark.py, docs/sweeps_from_paper.md:152-169): its default
+    heads (8 query / 1 kv, d=128, microbenchmark.py:136-138), bf16, (batch, prefix) of the paper's sweep, suffix 0 / 128 / 512,
+    operator captured in a HIP graph, 512 MB flush between timed replays; Hydragen vs the no-sharing baseline."""
+    from hydragen_amd.attention import hydragen_attention_nopad
+    from hydragen_amd.flash import flash_attention_seqlen
+
+    dev, dt, Hq, Hkv, D = "cuda:0", torch.bfloat16, 8, 1, 128
+    flush = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=dev)
+    rows = []
+    for B, P in ((512, 1024), (1024, 2048), (2048, 4096), (4096, 8192)):
+        q = torch.randn(B, 1, Hq, D, device=dev, dtype=dt)
+        sk, sv = torch.randn(1, P, Hkv, D, device=dev, dtype=dt), torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
+        k, v = torch.randn(B, 512, Hkv, D, device=dev, dtype=dt), torch.randn(B, 512, Hkv, D, device=dev, dtype=dt)
+        kt = torch.cat([sk.expand(B, -1, -1, -1), k], 1).contiguous()
+        vt = torch.cat([sv.expand(B, -1, -1, -1), v], 1).contiguous()
+        for S in (0, 128, 512):
+            lens = torch.full((B,), S, dtype=torch.int32, device=dev)
+            tl = lens + P
+            if S == 0:  # microbenchmark.py:76-83: no unique keys -> the prefix-only early exit (attention.py:273-274)
+                e = torch.empty(B, 0, Hkv, D, device=dev, dtype=dt)
+                gh = _capture(lambda: hydragen_attention_nopad(q, e, e, [sk], [sv]))
+            else:
+                ks, vs = k[:, :S], v[:, :S]
+                gh = _capture(lambda: hydragen_attention_nopad(q, ks, vs, [sk], [sv], seq_len=lens))
+            gn = _capture(lambda: flash_attention_seqlen(q, kt, vt, seq_len=tl))
+            h, n = _stats(_timed_replays(gh, iters, flush)), _stats(_timed_replays(gn, max(3, iters // 2), flush))
+            rows.append({"batch": B, "prefix": P, "suffix": S, "hydragen_us": h["mean_us"], "hydragen_rstd": h["rstd"],
+                         "nosharing_us": n["mean_us"], "speedup": n["mean_us"] / h["mean_us"]})
+            del gh, gn
+        del kt, vt, k, v
+        torch.cuda.empty_cache()
+    return {"heads": "8 q / 1 kv, d=128 (scripts/microbenchmark.py:136-138)", "iters": iters,
+            "protocol": "HIP-graph replay, 512 MB write flush before every timed replay (scripts/microbenchmark.py:24-47)", "rows": rows}
+
+
 def accuracy(ops, q, sk, sv, k, v, s):
     """Measured error of the bf16 operator at this shape, in both forms: 32 sequences x all heads against fp64 softmax
     attention over the concatenated [prefix; suffix] keys of the same bf16 inputs (torch, on the GPU)."""
@@ -644,13 +688,33 @@ def accuracy(ops, q, sk, sv, k, v, s):
     ops.out.zero_()
     ops.fused(s, torch.cuda.current_stream().cuda_stream)
     one = measure()
+    # the same with the prefix partial kept fp32 (hyd_decode_params.f32_partials): one rounding less, 16 MiB more traffic
+    st = torch.cuda.current_stream().cuda_stream
+    ops.out.zero_()
+    ops._call(s, "f32_partials", st)
+    f32p = measure()
+    f32p["us_back_to_back"] = _time_calls(lambda: ops._call(s, "f32_partials", st))
+    one["us_back_to_back"] = _time_calls(lambda: ops.fused(s, st))
     return {
         "dtype": "bf16", "suffix_len": s, "sequences": int(len(idx)),
         "reference": "fp64 softmax attention over [prefix; suffix] on the same bf16 inputs",
         **(two if ops.two_stream else one),
-        "one_call_form": one, "two_stream_form": two,
+        "one_call_form": one, "two_stream_form": two, "one_call_form_fp32_prefix_partial": f32p,
         "bf16_half_ulp_of_max_output": float(want.abs().max()) * 2.0 ** -9,
     }
+
+
+def _time_calls(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
 
 
 def model_decode(B, P, new_tokens):

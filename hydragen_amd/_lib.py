@@ -68,7 +68,7 @@ class DecodeParams(C.Structure):
         ("suffix", SuffixParams), ("levels", Level * HYD_MAX_LEVELS),
         ("n_levels", C.c_int32), ("phase", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("shared_max_workgroups", C.c_int32), ("reserved_", C.c_int32),
+        ("shared_max_workgroups", C.c_int32), ("f32_partials", C.c_int32),
     ]
 
 

@@ -222,6 +222,19 @@ def set_two_stream(mode: str) -> str:
     return prev
 
 
+_f32_partials = False
+
+
+def set_f32_partials(on: bool) -> bool:
+    """Keep every unsplit shared level's partial result in fp32 instead of the 16-bit dtype (hyd_decode_params.f32_partials):
+    one rounding less before the merge (C2, bf16: relative L2 error 2.85e-3 -> see bench.py `accuracy`) for 2 more bytes
+    per output element written and read back.  Default off: the reference itself merges 16-bit partials
+    (README.md:488-490).  Returns the previous setting."""
+    global _f32_partials
+    prev, _f32_partials = _f32_partials, bool(on)
+    return prev
+
+
 def _side_stream(device) -> "torch.cuda.Stream":
     key = (device.index if device.index is not None else torch.cuda.current_device(), threading.get_ident())
     st = _side_streams.get(key)
@@ -278,7 +291,7 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
     key = None
     stream = _stream()
     if not uncached:
-        key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), q.device.index, stream, threading.get_ident(),
+        key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), q.device.index, stream, threading.get_ident(), _f32_partials,
                tuple(_tensor_key(x) for x in shared_ks), tuple(_tensor_key(x) for x in shared_vs),
                tuple(_tensor_key(x) for x in shared_cu_seq_lens), tuple(shared_max_seq_lens), tuple(use_varlens))
         hit = _PARAM_CACHE.get(key)
@@ -290,6 +303,7 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
     p = DecodeParams()
     keep = [fill_suffix_params(p.suffix, q, k, v, seq_lens, out)]
     p.n_levels = len(shared_ks)
+    p.f32_partials = 1 if _f32_partials else 0
     for i, (sk, sv, scu, smax, uv) in enumerate(
         zip(shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens, use_varlens)
     ):

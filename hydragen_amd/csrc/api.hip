@@ -188,14 +188,14 @@ int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int gr
     return launch_prefix_w64(a, dtype, D, causal, grid, s);
 }
 
-int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s, int max_wgs = 0) {
+int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s, int max_wgs = 0, bool out_f32 = false) {
     PrefixArgs a;
     fill_prefix_args(p, pl, &a);
     const size_t rows = (size_t)p->B * p->nq * p->Hq;
     if (pl.nsplit == 1) {
         a.out = p->out;
         a.lse = p->lse;
-        a.out_f32 = 0;
+        a.out_f32 = out_f32 ? 1 : 0;  // only the decode entry asks for an fp32 partial (hyd_decode_params.f32_partials)
         a.lse_layout = p->lse_layout;
         int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, max_wgs, s);
         return rc ? fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc) : HYD_OK;
@@ -389,10 +389,11 @@ size_t unique_partial_bytes(const hyd_suffix_params& sp) {
 }
 
 // per-level workspace: nsplit == 1 -> one dtype slice + lse; nsplit > 1 -> fp32 slices (prefix_ws_bytes)
-size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl) {
+size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl, bool f32_partials) {
     const size_t rows = (size_t)pp.B * pp.nq * pp.Hq;
-    if (pl.nsplit > 1 && !level_is_small(pp, pl)) return prefix_ws_bytes(&pp, pl);
-    return align_up(rows * pp.D * 2, 256) + align_up(rows * 4, 256);
+    const bool small = level_is_small(pp, pl);
+    if (pl.nsplit > 1 && !small) return prefix_ws_bytes(&pp, pl);
+    return align_up(rows * pp.D * ((f32_partials && !small) ? 4 : 2), 256) + align_up(rows * 4, 256);
 }
 
 int check_prefix_ptrs(const hyd_prefix_params* p) {
@@ -590,7 +591,7 @@ size_t hyd_decode_workspace_bytes(const hyd_decode_params* p) {
         level_to_prefix(p, i, &pp);
         PrefixPlan pl;
         if (plan_prefix(&pp, &pl, level_split_cap(p->n_levels))) return 0;
-        total += level_ws_bytes(pp, pl);
+        total += level_ws_bytes(pp, pl, p->f32_partials != 0);
     }
     // the unique pass's own partial (HYD_PHASE_UNIQUE_PARTIAL / HYD_PHASE_MERGE: the two-stream form)
     if (p->n_levels > 0 && p->suffix.kv_len > 0) total += unique_partial_bytes(p->suffix);
@@ -622,6 +623,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
     if (p->n_levels < 0 || p->n_levels > HYD_MAX_LEVELS) return fail(HYD_ERR_BAD_ARG, "n_levels %d", p->n_levels);
     if (p->phase < HYD_PHASE_ALL || p->phase > HYD_PHASE_MERGE) return fail(HYD_ERR_BAD_ARG, "phase %d", p->phase);
     if (p->shared_max_workgroups < 0) return fail(HYD_ERR_BAD_ARG, "shared_max_workgroups %d", p->shared_max_workgroups);
+    if (p->f32_partials != 0 && p->f32_partials != 1) return fail(HYD_ERR_BAD_ARG, "f32_partials %d", p->f32_partials);
     const hyd_suffix_params& sp = p->suffix;
     int rc = check_suffix(&sp, true);
     if (rc) return rc;
@@ -664,7 +666,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         if ((rc = check_prefix_ptrs(&pps[i]))) return rc;
         if (pps[i].kv_len == 0) return fail(HYD_ERR_BAD_ARG, "level %d has kv_len == 0", i);
         small[i] = level_is_small(pps[i], pls[i]);
-        bytes[i] = level_ws_bytes(pps[i], pls[i]);
+        bytes[i] = level_ws_bytes(pps[i], pls[i], p->f32_partials != 0);
         need += bytes[i];
         n_parts += (pls[i].nsplit == 1 || small[i]) ? 1 : pls[i].nsplit;
     }
@@ -679,13 +681,14 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
     for (int i = 0; i < p->n_levels; ++i) {
         hyd_prefix_params& pp = pps[i];
         const PrefixPlan& pl = pls[i];
+        const bool part_f32 = p->f32_partials != 0 && !small[i];
         if (pl.nsplit == 1 || small[i]) {
             pp.out = ws;
-            pp.lse = reinterpret_cast<float*>(ws + align_up(rows * sp.D * 2, 256));
+            pp.lse = reinterpret_cast<float*>(ws + align_up(rows * sp.D * (part_f32 ? 4 : 2), 256));
             parts[i].out = pp.out;
             parts[i].lse = pp.lse;
             parts[i].count = 1;
-            parts[i].is_f32 = 0;
+            parts[i].is_f32 = part_f32 ? 1 : 0;
         } else {
             pp.workspace = ws;
             pp.workspace_bytes = bytes[i];
@@ -696,7 +699,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         }
         if (do_shared) {
             if (small[i]) rc = run_level_small(pp, pl, const_cast<void*>(parts[i].out), const_cast<float*>(parts[i].lse), s);
-            else rc = run_prefix(&pp, pl, /*merge=*/false, s, p->shared_max_workgroups);
+            else rc = run_prefix(&pp, pl, /*merge=*/false, s, p->shared_max_workgroups, part_f32);
             if (rc) return rc;
         }
         ws += bytes[i];

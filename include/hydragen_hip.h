@@ -181,7 +181,9 @@ typedef struct hyd_decode_params {
     size_t workspace_bytes;
     int32_t shared_max_workgroups; /* 0 = one workgroup per unit of a prefix pass (the whole chip); > 0: at most
                                     * that many persistent workgroups, one per CU, walk the units           */
-    int32_t reserved_;
+    int32_t f32_partials;          /* 0: an unsplit level's partial is stored in the 16-bit dtype (what the reference
+                                    * does: its flash-attn output is 16-bit, README.md:488-490); 1: kept fp32 (one
+                                    * rounding less, + 2 bytes per output element written and read back)           */
 } hyd_decode_params;
 
 HYD_API size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);

@@ -4,11 +4,22 @@ import torch
 
 TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
 
-# Tolerances.  fp16: the reference's own bar (tests/test_attention.py:36-38,185).
-# bf16 has 3 fewer mantissa bits than fp16 -> 8x the absolute bound; mean relative bound stated
-# against the float64 oracle on identical (bf16-rounded) inputs.
-ATOL = {"f16": 2e-3, "bf16": 1.6e-2}
+# Tolerances.  fp16: the reference's own bar (tests/test_attention.py:36-38,182-187): every |d| <= 2e-3, mean rdiff <= 5e-3.
+# bf16 (8 mantissa bits; the reference states no bf16 bar): every |d| <= 4 half-ulps of the largest expected output,
+# i.e. max|want| * 2^-7 (one output rounding is 1 half-ulp; measured at C2: 2.9 half-ulps), mean rdiff <= 1e-2 and
+# relative L2 error <= 5e-3 against the float64 oracle on identical (bf16-rounded) inputs -- set from the 8000-seed
+# soak (tools/soak.py: relative L2 peaks at 3.4e-3) and the C2 measurement (2.85e-3, bench.py `accuracy`).
+ATOL = {"f16": 2e-3}
 RTOL_MEAN = {"f16": 5e-3, "bf16": 1e-2}
+REL_L2 = {"f16": 1e-3, "bf16": 5e-3}
+
+
+def atol(dtype, want):
+    """Absolute bound for a tensor whose exact values are `want` (numpy or torch)."""
+    if dtype == "f16":
+        return ATOL["f16"]
+    n = want.numel() if hasattr(want, "numel") else want.size
+    return (float(abs(want).max()) if n else 0.0) * 2.0 ** -7
 
 
 def dev(x, dtype=None, device="cuda:0"):
@@ -46,17 +57,18 @@ def assert_close(got, want, dtype, what="", rtol_mean=None):
     err = np.abs(got - want).max()
     mrd = rdiff(got, want).mean()
     rt = RTOL_MEAN[dtype] if rtol_mean is None else rtol_mean
-    assert err <= ATOL[dtype] and mrd <= rt, f"{what}: max abs {err:.3e} mean rdiff {mrd:.3e}"
+    bound = atol(dtype, want)
+    l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+    assert err <= bound and mrd <= rt, f"{what}: max abs {err:.3e} (bound {bound:.3e}) mean rdiff {mrd:.3e}"
+    if dtype == "bf16":
+        assert l2 <= REL_L2["bf16"], f"{what}: relative L2 {l2:.3e}"
     return err, mrd
 
 
-REL_L2 = {"f16": 1e-3, "bf16": 8e-3}
-
-
 def assert_close_l2(got, want, dtype, what=""):
-    """Maximum absolute error (the reference's atol, x 2^3 for bf16, scaled by max |want| when outputs exceed 1: the
-    bound is ~2 ulp of the storage dtype at magnitude 1) and relative L2 error ||got - want|| / ||want||
-    <= 1e-3 for fp16 (the figure BASELINE.json states), x 2^3 for bf16.  Used where tensors are small: the
+    """Maximum absolute error (fp16: the reference's atol, scaled by max |want| when outputs exceed 1; bf16: 4 half-ulps of
+    max |want|) and relative L2 error ||got - want|| / ||want|| <= 1e-3 for fp16 (the figure BASELINE.json states),
+    5e-3 for bf16.  Used where tensors are small: the
     reference's third figure, the MEAN element-wise relative difference (tests/test_attention.py:183-185), is kept
     for the reference-shaped cases but is dominated by outputs near zero on tensors of a few hundred elements (a
     5000-seed soak, tools/soak.py: relative L2 peaks at 4.0e-4 / 3.3e-3 while the mean relative difference of the
@@ -66,6 +78,6 @@ def assert_close_l2(got, want, dtype, what=""):
     assert got.shape == want.shape and np.isfinite(got).all(), what
     err = np.abs(got - want).max()
     l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
-    atol = ATOL[dtype] * max(1.0, float(np.abs(want).max()))
-    assert err <= atol and l2 <= REL_L2[dtype], f"{what}: max abs {err:.3e} (bound {atol:.3e}) relative L2 {l2:.3e}"
+    bound = ATOL["f16"] * max(1.0, float(np.abs(want).max())) if dtype == "f16" else atol(dtype, want)
+    assert err <= bound and l2 <= REL_L2[dtype], f"{what}: max abs {err:.3e} (bound {bound:.3e}) relative L2 {l2:.3e}"
     return err, l2

@@ -56,6 +56,23 @@ def timed(fn, iters, flush=None, clean=None):
     return t.mean().item(), t.std().item()
 
 
+def rel_l2(out, q, k, v, sks, svs, S, nseq=8):
+    """Relative L2 error of `out` on `nseq` sequences (all heads) against fp64 softmax attention over the concatenated
+    [level 0; level 1; ...; unique] keys of the same rounded inputs (sequence b uses group b // (B / sb) of every level,
+    /root/reference/hydragen/attention.py:264-268)."""
+    B, _, Hq, D = q.shape
+    g = Hq // k.shape[2]
+    idx = torch.linspace(0, B - 1, min(nseq, B), device=q.device).long()
+    ks = [sk[idx // (B // sk.shape[0])] for sk in sks] + [k[idx, :S]]
+    vs = [sv[idx // (B // sv.shape[0])] for sv in svs] + [v[idx, :S]]
+    kk = torch.cat(ks, 1).double().repeat_interleave(g, 2)
+    vv = torch.cat(vs, 1).double().repeat_interleave(g, 2)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q[idx].double(), kk) / D ** 0.5
+    want = torch.einsum("bhqk,bkhd->bqhd", sc.softmax(-1), vv)
+    got = out[idx].double()
+    return float((got - want).norm() / want.norm()), float((got - want).abs().max() / want.abs().max())
+
+
 def fmt(m, s):
     r = s / m if m > 0 else 0.0
     return f"{m:9.1f} ± {s:5.1f}{' (rstd>10%!)' if r > 0.10 else ''}"
@@ -75,8 +92,11 @@ def main():
         "the Infinity Cache whose write-back lands in the timed call.  Cold = the same flush followed by a 512 MB read-only pass:",
         "nothing of the call's data is cached and nothing is waiting to be written back.",
         "",
-        "| config | hydragen us (back to back) | hydragen us (flushed) | hydragen us (cold) | no-sharing us (flushed) | speed-up (flushed) | hydragen KV bytes | effective GB/s (cold) |",
-        "|---|---|---|---|---|---|---|---|",
+        "rel L2 / max = relative L2 error and max |error| / max |exact| of the operator's output on 8 sequences x all heads against fp64 attention",
+        "over the concatenated keys of the same rounded inputs (one bf16 output rounding alone: 1.1e-3 / <= 2^-9 = 2.0e-3).",
+        "",
+        "| config | hydragen us (back to back) | hydragen us (flushed) | hydragen us (cold) | no-sharing us (flushed) | speed-up (flushed) | hydragen KV bytes | effective GB/s (cold) | rel L2 / max |",
+        "|---|---|---|---|---|---|---|---|---|",
     ]
     g = torch.Generator(device=DEV).manual_seed(0)
     for name, B, levels, S, Hq, Hkv, D, dt in CONFIGS:
@@ -87,6 +107,7 @@ def main():
         sks, svs = [r(sb, P, Hkv, D) for sb, P in levels], [r(sb, P, Hkv, D) for sb, P in levels]
         lens = torch.full((B,), S, dtype=torch.int32, device=DEV)
         hyd = lambda: hydragen_attention_nopad(q, k, v, sks, svs, seq_len=lens)
+        l2, mx = rel_l2(hyd(), q, k, v, sks, svs, S)
         hm, hs = timed(hyd, a.iters)
         fm, fs = timed(hyd, a.iters, flush)
         cm, cs = timed(hyd, a.iters, flush, clean)
@@ -108,7 +129,7 @@ def main():
         torch.cuda.empty_cache()
         sp = f"{nm / fm:5.1f}x" if nm else "n/a (KV > HBM budget)"
         nstr = fmt(nm, ns) if nm else f"({ns_bytes / 1e9:.0f} GB of KV)"
-        lines.append(f"| {name} | {fmt(hm, hs)} | {fmt(fm, fs)} | {fmt(cm, cs)} | {nstr} | {sp} | {kv_bytes / 2**20:.0f} MiB | {kv_bytes / cm / 1e3:.0f} |")
+        lines.append(f"| {name} | {fmt(hm, hs)} | {fmt(fm, fs)} | {fmt(cm, cs)} | {nstr} | {sp} | {kv_bytes / 2**20:.0f} MiB | {kv_bytes / cm / 1e3:.0f} | {l2:.2e} / {mx:.2e} |")
         print(lines[-1], flush=True)
     txt = "\n".join(lines) + "\n"
     if a.out:
