@@ -95,6 +95,14 @@ def suffix_schedule(steps: int, smax: int) -> list[int]:
     return [1 + int((((i + 0.5) * c / steps) % 1.0) * smax) for i in range(steps)]
 
 
+def launch_schedule(steps: int, warmup: int, trials: int, smax: int) -> list[int]:
+    """Suffix length of EVERY launch of the operator in a run with the untimed legs switched off (what a profiler sees):
+    3 eager warm-ups + 1 capture per distinct length (`_capture`; a capture records, it does not launch), the warm-up
+    steps, the timed steps, the repeats."""
+    sched, warm = suffix_schedule(steps, smax), suffix_schedule(max(warmup, 1), smax)[:warmup]
+    return [s for s in sorted(set(sched + suffix_schedule(max(warmup, 1), smax))) for _ in range(3)] + warm + sched * (1 + trials)
+
+
 def describe_schedule(sched: list[int]) -> str:
     if len(sched) <= 32:
         return ",".join(map(str, sched))

@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
 def main(path, tag, steps, warmup):
-    from bench import suffix_schedule
+    from bench import launch_schedule
 
     B, P, S, Hq, Hkv, D, e = 1024, 2048, 128, 32, 32, 128, 2
     vals = {}
@@ -23,13 +23,13 @@ def main(path, tag, steps, warmup):
                 kern = "suffix" if "suffix_attn" in line else "prefix" if "prefix_attn" in line else None
                 if kern:
                     vals[(kern, c)] = float(parts[i + 2])
-    launches = suffix_schedule(max(warmup, 1), S)[:warmup] + suffix_schedule(steps, S)
+    launches = launch_schedule(steps, warmup, 0, S)  # the profiled command runs with --trials 0
     suf_alg = sum(2 * e * Hkv * D * B * s + 2 * B * Hq * D * e + 4 * B * Hq for s in launches) / len(launches)
     pre_alg = 2 * P * Hkv * D * e + 2 * B * Hq * D * e + 4 * B * Hq
     out = {
         "source": f"profiles/{tag}_pmc.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py "
-        f"--steps {steps} --warmup {warmup}` (untimed legs off); per-launch mean over the {warmup} warm-up + {steps} timed "
-        "launches; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md",
+        f"--steps {steps} --warmup {warmup} --trials 0` (untimed legs off); per-launch mean over all {len(launches)} launches of the run "
+        "(capture warm-ups, warm-up steps, timed steps: bench.launch_schedule); FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md",
         "steps": steps, "warmup": warmup, "batch": B, "prefix": P, "max_suffix": S, "qheads": Hq, "kvheads": Hkv,
         "suffix_algorithmic_bytes_per_launch": suf_alg, "prefix_algorithmic_bytes_per_launch": pre_alg,
     }

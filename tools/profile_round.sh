@@ -13,12 +13,12 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-protocol --no-model --no-accuracy"
+CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --trials 0 --no-cpu-baseline --no-protocol --no-model --no-accuracy --no-paper-sweep"
 cd /tmp
 rm -rf /tmp/prof_*
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o run -- $CMD > $OUT/${TAG}_bench_profiled.json 2>/tmp/prof_stats.log
 DB=$(find /tmp/prof_stats -name '*.db' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- $CMD"; echo "# (averages are over the $WARM warm-up + $STEPS timed launches; both follow bench.py's uniform suffix schedule)"; python $REPO/tools/rocprof_summary.py stats $DB; } > $OUT/${TAG}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- $CMD"; echo "# (averages are over every launch of the run: 3 eager warm-ups per captured suffix length, $WARM warm-up steps, $STEPS timed steps -- bench.launch_schedule; mean suffix $(python -c "import sys; sys.path.insert(0, \"$REPO\"); import bench; l = bench.launch_schedule($STEPS, $WARM, 0, 128); print(round(sum(l) / len(l), 2), len(l))") = mean, launches)"; python $REPO/tools/rocprof_summary.py stats $DB; } > $OUT/${TAG}_kernel_stats.txt
 {
 echo "# rocprofv3 --pmc passes (separate runs of: $CMD). FETCH_SIZE/WRITE_SIZE in KB per launch; gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)"
 for C in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY"; do
