@@ -752,6 +752,27 @@ def model_decode(B, P, new_tokens):
         pre = min(run(1, **kw) for _ in range(2))
         return full, pre, full - pre
 
+    def small_batch_modes(Bs=128, new=64):
+        """hydragen vs hydragen_noshared (scripts/synth.py:112,151: the prefix KV replicated into every sequence's unique
+        cache, llama.py:264-298) at the largest batch whose replicated prefix fits in HBM comfortably (1.1 GB per sequence)."""
+        out = {"batch": Bs, "new_tokens": new}
+        for name, kw, extra in (("hydragen", {}, 0), ("hydragen_noshared", {"disable_hydragen": True}, P)):
+            model.setup_caches(max_unique_batch_size=Bs, max_unique_seq_length=new + 16 + extra, max_shared_batch_sizes=[1],
+                               max_shared_seq_lengths=[P])
+
+            def go(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.generate(input_ids=prompt, num_return_sequences=Bs, max_new_tokens=n, temperature=100.0, **kw)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+
+            go(4)
+            d = go(new) - go(1)
+            out[name] = {"decode_s": d, "decode_tokens_per_s": Bs * (new - 1) / d, "ms_per_decode_step": d / (new - 1) * 1e3}
+        out["speedup_vs_noshared"] = out["hydragen"]["decode_tokens_per_s"] / out["hydragen_noshared"]["decode_tokens_per_s"]
+        return out
+
     full, pre, dec = mode()
     # upper bound of scripts/synth.py:111-115 ("noattention": attention replaced by identity on q, llama.py:433-437)
     _, _, dec_na = mode(disable_attention=True)
@@ -764,7 +785,8 @@ def model_decode(B, P, new_tokens):
         "noattention": {"decode_s": dec_na, "decode_tokens_per_s": B * steps / dec_na, "ms_per_decode_step": dec_na / steps * 1e3},
         "fraction_of_noattention_bound": dec_na / dec,
         "attention_us_per_layer_step": (dec - dec_na) / steps / layers * 1e6,
-        "protocol": "scripts/synth.py:33-79,111-115,207-226 (modes hydragen and noattention)",
+        "small_batch_modes": small_batch_modes(),
+        "protocol": "scripts/synth.py:33-79,111-115,148-178,207-226 (modes hydragen, noattention; hydragen_noshared at the batch that fits)",
     }
 
 

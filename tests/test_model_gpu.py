@@ -93,6 +93,20 @@ def test_rope_append_kernel_vs_torch():
         assert kc[mask].abs().max() == 0 and vc[mask].abs().max() == 0   # nothing else was touched
 
 
+@pytest.mark.parametrize("spec", ["prefix+completions", "three-level", "padded-shared"])
+def test_decode_graph_with_the_two_stream_form_in_every_layer(spec):
+    """The decode graph captured with the two-stream form forced on (a fork and a join inside every layer's attention,
+    shared phase on a side stream) and with fp32 prefix partials: same logits check as the one-call form."""
+    from hydragen_amd import attention as A
+
+    prev, prev_f32 = A.set_two_stream("on"), A.set_f32_partials(True)
+    try:
+        test_decode_logits_vs_fp32_transformer(torch.bfloat16, True, spec)
+    finally:
+        A.set_two_stream(prev)
+        A.set_f32_partials(prev_f32)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("spec", ["prefix+completions", "three-level", "padded-shared", "prefix+suffix"])

@@ -145,3 +145,26 @@ def test_two_stream_form_is_chosen_and_correct_under_graph_capture():
     want2 = A.hydragen_attention_nopad(q, k, v, [sk], [sv], sl)
     torch.cuda.synchronize()
     assert (out.float() - want2.float()).abs().max().item() <= atol("bf16", want2.float()) / 2
+
+
+@pytest.mark.parametrize("name,kw", CASES, ids=[c[0] for c in CASES])
+def test_f32_partials_vs_golden(name, kw):
+    """hyd_decode_params.f32_partials: unsplit levels keep their partial in fp32 (one rounding less than the reference's
+    16-bit flash-attn outputs, README.md:488-490); same fixtures, same bounds, one-call and two-stream form."""
+    from hydragen_amd import attention as A
+
+    case = make_case(**kw)
+    g = load_golden(name)
+    d = case_to_device(case)
+    prev = A.set_f32_partials(True)
+    try:
+        for mode in ("off", "on"):
+            pm = A.set_two_stream(mode)
+            try:
+                out = A.hydragen_attention(**d)
+                torch.cuda.synchronize()
+            finally:
+                A.set_two_stream(pm)
+            assert_close(out.float().cpu().numpy(), g["out_exact"], case["dtype"], f"{name} f32 partials, two-stream {mode}")
+    finally:
+        A.set_f32_partials(prev)
