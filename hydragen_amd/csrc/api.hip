@@ -54,7 +54,7 @@ int check_scale(float s) {
 
 int check_common(int dtype, int B, int nq, int Hq, int Hkv, int D) {
     if (dtype != HYD_F16 && dtype != HYD_BF16) return fail(HYD_ERR_UNSUPPORTED, "dtype %d: only f16/bf16", dtype);
-    if (D != 64 && D != 128) return fail(HYD_ERR_UNSUPPORTED, "head_dim %d: only 64 and 128 are implemented", D);
+    if (D != 64 && D != 128 && D != 256) return fail(HYD_ERR_UNSUPPORTED, "head_dim %d: only 64, 128 and 256 are implemented", D);
     if (B <= 0 || nq <= 0 || Hq <= 0 || Hkv <= 0) return fail(HYD_ERR_BAD_ARG, "non-positive size B=%d nq=%d Hq=%d Hkv=%d", B, nq, Hq, Hkv);
     if (Hq % Hkv != 0) return fail(HYD_ERR_BAD_ARG, "qheads %d not divisible by kvheads %d", Hq, Hkv);
     return HYD_OK;
@@ -88,7 +88,7 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMa
         // K/V staging per flop and no cross-half merge.
         const int force_rows = dev_switch("HYD_PREFIX_ROWS");  // 0 in product builds
         const int64_t units128 = (int64_t)p->sb * p->Hkv * pl->row_blocks;
-        const bool can = true;
+        const bool can = p->D != 256;  // D = 256: one query block per wave, 128-row workgroups only
         if (can && (force_rows == 256 || (force_rows == 0 && units128 > kNumCU))) {
             pl->wg_rows = 256;
             pl->row_blocks = (int)((mrows + 255) / 256);

@@ -89,13 +89,19 @@ __device__ __forceinline__ float dpp_f32(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xf, 0xf, false));
 }
 
-// all-reduce (sum) over aligned groups of LANES (8 or 16) consecutive lanes, DPP only
+// all-reduce (sum) over aligned groups of LANES (8, 16 or 32) consecutive lanes: DPP inside a 16-lane row, one
+// v_permlane16_swap (both lanes receive the ordered pair of the two rows' values) across the rows of a 32-lane group
 template <int LANES>
 __device__ __forceinline__ float group_sum(float x) {
     x += dpp_f32<0xB1>(x);   // quad_perm [1,0,3,2]
     x += dpp_f32<0x4E>(x);   // quad_perm [2,3,0,1]
     x += dpp_f32<0x141>(x);  // row_half_mirror
-    if (LANES == 16) x += dpp_f32<0x140>(x);  // row_mirror
+    if (LANES >= 16) x += dpp_f32<0x140>(x);  // row_mirror
+    if (LANES == 32) {
+        const int xi = __builtin_bit_cast(int, x);
+        auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+        x = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+    }
     return x;
 }
 

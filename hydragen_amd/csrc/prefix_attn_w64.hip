@@ -1,13 +1,12 @@
-// Prefix pass kernel + launcher: the unit body lives in prefix_unit_w64.h (it is also the prefix role of the co-run
-// kernel, corun_attn.hip).  Replaces flash-attn's _flash_attn_forward / _flash_attn_varlen_forward as called from
+// Prefix pass kernel + launcher: the unit body lives in prefix_unit_w64.h.  Replaces flash-attn's _flash_attn_forward / _flash_attn_varlen_forward as called from
 // /root/reference/hydragen/flash.py:284-351 and hydragen/attention.py:270,313,344.
 #include "prefix_unit_w64.h"
 
 namespace hyd {
 
 // One workgroup per unit (grid == a.vgrid), or -- when the caller asks for fewer workgroups than units -- persistent
-// workgroups that walk the units with a stride of the grid (development switch HYD_PREFIX_PERSIST; the co-run kernel
-// of corun_attn.hip hands units to its prefix role through a queue instead).
+// workgroups that walk the units with a stride of the grid (hyd_decode_params.shared_max_workgroups: the two-stream form
+// keeps the prefix pass to a part of the chip).
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
 __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -42,6 +41,11 @@ int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int gr
 #endif
 #define HYD_DISPATCH(TT, DD, KK) \
     return causal ? launch_prefix_w64_t<TT, DD, true, KK>(a, grid, s) : launch_prefix_w64_t<TT, DD, false, KK>(a, grid, s)
+    if (D == 256) {  // one query block per wave: 128 rows per workgroup, every wave walks all keys (KG = 1)
+        if (a.wg_rows != 128) return (int)hipErrorInvalidValue;
+        if (dtype == HYD_F16) { HYD_DISPATCH(F16, 256, 1); }
+        HYD_DISPATCH(BF16, 256, 1);
+    }
     if (a.wg_rows == 256) {
         if (dtype == HYD_F16) {
             if (D == 128) { HYD_DISPATCH(F16, 128, 1); }

@@ -459,14 +459,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ABL: development-only timing ablations (bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
 // bit4 no barrier in the loop, bit5 no exp2, bit6 no element phase, bit7 no row sums / pack); only ABL = 0 ships.
-template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
+// QB: 32-row query blocks per wave.  2 for D <= 128 (64 rows per wave); 1 for D = 256, where one block's O accumulators
+// (8 x 16) and Q fragments (16 x 4) fill the same a[0:191] that two blocks fill at D = 128 (then always KG = 1: 128
+// rows per workgroup, every wave walks all keys, 128 KB of rings).
+template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, int QB = (D > 128 ? 1 : 2)>
 __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
-    constexpr int QB = 2;                // 32-row query blocks per wave
+    static_assert(QB == 1 || QB == 2, "query blocks per wave");
+    static_assert(D <= 128 || (QB == 1 && KG == 1), "D = 256 runs one query block per wave and unsplit key tiles");
+    constexpr int WROWS = 32 * QB;       // query rows per wave
     constexpr int RB = D * 2;            // bytes per K/V row
     constexpr int NC = D / 16;           // k-chunks of the QK^T contraction
     constexpr int NDB = D / 32;          // 32-wide d blocks of O^T
-    constexpr int RWG = KG == 2 ? 128 : 256;                 // query rows per workgroup
+    constexpr int RWG = (KG == 2 ? 2 : 4) * WROWS;            // query rows per workgroup
     constexpr int BROWS = KG == 2 ? 64 : 32;                  // K (or V) rows staged per iteration
     constexpr int NLB = BROWS * RB / 1024 / 4;                // DMA instructions per wave per tensor per iteration
     constexpr int RPI = 1024 / RB;                            // rows per DMA instruction
@@ -550,7 +555,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     // copy of the lane index, so that the row's token / head / output offset are not carried across the pipeline (the
     // loop runs within a handful of registers of the 256-VGPR line; beyond it hipcc parks values in the asm-owned AGPRs).
     auto row_of = [&](int qb, int l31_, bool& valid, int& tok, int& hqv, int64_t& off) __attribute__((always_inline)) {
-        const int r = rb * RWG + rw * 64 + qb * 32 + l31_;
+        const int r = rb * RWG + rw * WROWS + qb * 32 + l31_;
         valid = r < Mrows;
         const int rc = min(r, Mrows - 1);
         tok = rc / a.g;  // query token inside the group
@@ -590,14 +595,14 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     auto slot_v = [](int s) { return KG == 2 ? (s >> 1) * V_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
 
     // ---- per-lane LDS byte addresses of the MFMA fragments (ring slot 0) -------------------------------
-    const int ksw = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);
+    const int ksw = D >= 128 ? (l31 & 15) : ((l31 >> 1) & 7);
     const int kx = hi ^ ksw;
     unsigned kaddr[NC];  // K fragment c of row l31 in slot 0 of this wave's key half (KA or KB)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
         kaddr[c] = (unsigned)(uintptr_t)(lptr_c)(smem + (kg ? KB_OFF : KA_OFF) + l31 * RB + (((2 * c) ^ kx) << 4));
     const int i16 = lane & 15, g16 = lane >> 4;
-    const int vsw = D == 128 ? (i16 >> 2) : ((i16 >> 3) & 1);
+    const int vsw = D >= 128 ? (i16 >> 2) : ((i16 >> 3) & 1);
     unsigned vaddr[NDB];  // V^T fragment address in slot 0 for key slot 0 of this wave's half
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -617,8 +622,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     for (int i = 0; i < NLB; ++i) {
         const int q = wave * NLB + i;
         const int rr = q * RPI + drow, h = KG == 2 ? rr >> 5 : 0, r32 = rr & 31;
-        const int kch = D == 128 ? (dcp ^ (r32 & 15)) : (dcp ^ ((r32 >> 1) & 7));
-        const int vs_ = D == 128 ? (r32 & 3) : ((r32 >> 1) & 1);
+        const int kch = D >= 128 ? (dcp ^ (r32 & 15)) : (dcp ^ ((r32 >> 1) & 7));
+        const int vs_ = D >= 128 ? (r32 & 3) : ((r32 >> 1) & 1);
         const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
         const int drr = h * 64 + r32;  // row inside the 128-key tile (KG = 2) / the block (KG = 1)
         koffb[i] = (unsigned)(((int64_t)drr * a.k_ts + kch * 8) * 2);
@@ -719,7 +724,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         }
         if constexpr (SM && MASK) {
             bool need_mask = !bvalid || (kw + 32 > kend);
-            if (CAUSAL) need_mask = need_mask || __builtin_amdgcn_ballot_w64(min(row_lim[0], row_lim[1]) < kw + 31) != 0ull;
+            if (CAUSAL) need_mask = need_mask || __builtin_amdgcn_ballot_w64(min(row_lim[0], row_lim[QB - 1]) < kw + 31) != 0ull;
             if (need_mask) {
                 asm volatile("" ::: "memory");  // keep this a (cold) branch
 #pragma unroll
@@ -814,7 +819,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
             });
             if constexpr (SM && !(ABL & 4) && (j * NG) / NSLOT <= 1 && 1 < ((j + 1) * NG) / NSLOT) {
                 // both query blocks know their lane maxima: adopt a new reference maximum?  (cold, wave-uniform)
-                if (__builtin_amdgcn_ballot_w64(upf[0] || upf[1]) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(upf[0] || upf[QB - 1]) != 0ull) {
                     asm volatile("" ::: "memory");  // keep this a branch
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
@@ -976,7 +981,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         });
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            mlbuf[(wave * QB + qb) * 128 + lane] = m_raw[qb] * sc;
+            mlbuf[(wave * QB + qb) * 128 + lane] = l_tot[qb] > 0.f ? m_raw[qb] * sc : -INFINITY;
             mlbuf[(wave * QB + qb) * 128 + 64 + lane] = l_tot[qb];
         }
         __syncthreads();
@@ -993,7 +998,13 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         row_of(qb, lane_e, rvalid_q, rtok_q, hq_q, row_off_q);
         const float m1 = KG == 2 ? mlbuf[(pw * QB + qb) * 128 + lane] : -INFINITY;
         const float l1 = KG == 2 ? mlbuf[(pw * QB + qb) * 128 + 64 + lane] : 0.f;
-        const float m_own = m_raw[qb] * sc;  // base-2 exponent units
+        // base-2 exponent units.  Opaque to the optimiser: with the product folded into `m_own - mfs` as an fma, a wave
+        // that saw no key (m_raw = kMinit, e.g. the empty split of a short ragged group) would compute exp2 of the
+        // PRODUCT'S ROUNDING ERROR (~1e21) instead of exp2(0) -- inf * 0 = NaN for scales whose error is positive
+        // (found at D = 256).  A wave without keys also reports -inf, so that it drops out of the merge exactly.
+        float m_own = m_raw[qb] * sc;
+        asm volatile("" : "+v"(m_own));
+        if (!(l_tot[qb] > 0.f)) m_own = -INFINITY;
         const float mf = fmaxf(m_own, m1);
         const float mfs = (mf == -INFINITY) ? 0.f : mf;
         const float a0 = fast_exp2(m_own - mfs), a1 = fast_exp2(m1 - mfs);

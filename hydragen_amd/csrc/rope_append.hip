@@ -86,10 +86,12 @@ int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s) {
     if (dtype == HYD_F16) {
         if (D == 128) HYD_ROPE(F16, 128);
         else if (D == 64) HYD_ROPE(F16, 64);
+        else if (D == 256) HYD_ROPE(F16, 256);
         else return (int)hipErrorInvalidValue;
     } else {
         if (D == 128) HYD_ROPE(BF16, 128);
         else if (D == 64) HYD_ROPE(BF16, 64);
+        else if (D == 256) HYD_ROPE(BF16, 256);
         else return (int)hipErrorInvalidValue;
     }
 #undef HYD_ROPE

@@ -372,9 +372,11 @@ int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s) {
     if (dtype == HYD_F16) {
         if (D == 128) return launch_suffix_t<F16, 128>(a, s);
         if (D == 64) return launch_suffix_t<F16, 64>(a, s);
+        if (D == 256) return launch_suffix_t<F16, 256>(a, s);
     } else {
         if (D == 128) return launch_suffix_t<BF16, 128>(a, s);
         if (D == 64) return launch_suffix_t<BF16, 64>(a, s);
+        if (D == 256) return launch_suffix_t<BF16, 256>(a, s);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -67,10 +67,10 @@ def _q_contig(q: Tensor) -> Tensor:
     return q.contiguous()
 
 
-# ---- head dims other than the kernels' 64 / 128 -------------------------------------------------------------------
-# flash-attn takes any head_dim that is a multiple of 8 (flash.py:295-304 hands it whatever the model has).  The HIP
-# kernels are instantiated for 64 and 128; other multiples of 8 below 128 run zero-PADDED to the next of the two with
-# the TRUE head dim's softmax scale (hyd_*_params.softmax_scale): zero columns add nothing to q.k and produce zero
+# ---- head dims other than the kernels' 64 / 128 / 256 ---------------------------------------------------------------
+# flash-attn takes any head_dim that is a multiple of 8 up to 256 (flash.py:295-304 hands it whatever the model has).
+# The HIP kernels are instantiated for 64, 128 and 256; other multiples of 8 run zero-PADDED to the next of the three
+# with the TRUE head dim's softmax scale (hyd_*_params.softmax_scale): zero columns add nothing to q.k and produce zero
 # output columns, which are cut off again.  Functional, not fast: q, k and v are copied on every call -- a model with
 # such a head dim should keep its caches padded instead.
 # forwarded to the C ABI by the marshalling helpers below; 0 = head_dim ** -0.5.  A context variable: two threads (or
@@ -83,11 +83,11 @@ def current_softmax_scale() -> float:
 
 
 def padded_head_dim(d: int) -> int:
-    if d in (64, 128):
+    if d in (64, 128, 256):
         return d
-    if d <= 0 or d % 8 or d > 128:
-        raise NotImplementedError(f"head_dim {d}: multiples of 8 up to 128 are implemented")
-    return 64 if d < 64 else 128
+    if d <= 0 or d % 8 or d > 256:
+        raise NotImplementedError(f"head_dim {d}: multiples of 8 up to 256 are implemented (as in flash-attn)")
+    return 64 if d < 64 else 128 if d < 128 else 256
 
 
 def pad_head_dim(t: Tensor, dp: int) -> Tensor:

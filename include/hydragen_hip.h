@@ -29,7 +29,7 @@
  *     message for the calling thread's last failure;
  *   - 16-bit dtypes: HYD_F16 (IEEE half) and HYD_BF16; accumulation, softmax and LSE are fp32.
  *   - q/out are [B, nq, Hq, D] contiguous; K/V tensors are token-major with explicit element
- *     strides and a contiguous head_dim; supported head_dim: 64, 128.
+ *     strides and a contiguous head_dim; supported head_dim: 64, 128, 256.
  */
 #ifndef HYDRAGEN_HIP_H
 #define HYDRAGEN_HIP_H

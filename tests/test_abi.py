@@ -203,11 +203,12 @@ def test_product_sources_never_touch_the_oracle():
 
 
 def test_head_dim_padding_rule():
-    """Which head dims the Python mirrors accept (hydragen_amd/flash.py): 64 / 128 natively, other multiples of 8 up to 128
-    padded to the next of the two, everything else refused like an unsupported shape."""
+    """Which head dims the Python mirrors accept (hydragen_amd/flash.py): 64 / 128 / 256 natively, other multiples of 8 up
+    to 256 (flash-attn's range) padded to the next of the three, everything else refused like an unsupported shape."""
     from hydragen_amd.flash import padded_head_dim
 
-    assert [padded_head_dim(d) for d in (8, 56, 64, 72, 80, 96, 120, 128)] == [64, 64, 64, 128, 128, 128, 128, 128]
-    for d in (0, 4, 100, 136, 256):
+    assert [padded_head_dim(d) for d in (8, 56, 64, 72, 80, 96, 120, 128, 136, 248, 256)] == \
+        [64, 64, 64, 128, 128, 128, 128, 128, 256, 256, 256]
+    for d in (0, 4, 100, 264, 512):
         with pytest.raises(NotImplementedError):
             padded_head_dim(d)

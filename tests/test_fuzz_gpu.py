@@ -48,11 +48,13 @@ def _draw(seed):
 check_fuzz = assert_close_l2
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", list(range(48)) + [1000 + i for i in range(16)])
 def test_random_hierarchy_vs_oracle(seed):
     from hydragen_amd.attention import hydragen_attention
 
-    kw, prefill = _draw(seed)
+    kw, prefill = _draw(seed % 1000)
+    if seed >= 1000:  # the same hierarchies at head_dim 256 (one query block per wave / 32 lanes per key)
+        kw["dim"] = 256
     case = make_case(**kw)
     if prefill:
         case["seq_lens"] = None

@@ -93,6 +93,12 @@ def test_rope_append_kernel_vs_torch():
         assert kc[mask].abs().max() == 0 and vc[mask].abs().max() == 0   # nothing else was touched
 
 
+def test_decode_logits_head_dim_256():
+    """A model with 256-wide heads (flash-attn's upper limit, flash.py:295-304): the D = 256 instantiations of the prefix
+    pass, the suffix pass and the fused RoPE + append kernel under the decode graph."""
+    test_decode_logits_vs_fp32_transformer(torch.bfloat16, True, "three-level", head_dim=256)
+
+
 @pytest.mark.parametrize("spec", ["prefix+completions", "three-level", "padded-shared"])
 def test_decode_graph_with_the_two_stream_form_in_every_layer(spec):
     """The decode graph captured with the two-stream form forced on (a fork and a join inside every layer's attention,
@@ -110,8 +116,8 @@ def test_decode_graph_with_the_two_stream_form_in_every_layer(spec):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("spec", ["prefix+completions", "three-level", "padded-shared", "prefix+suffix"])
-def test_decode_logits_vs_fp32_transformer(dtype, graph, spec):
-    model = make_model(dtype, head_dim=64 if dtype == torch.float16 else 128)
+def test_decode_logits_vs_fp32_transformer(dtype, graph, spec, head_dim=None):
+    model = make_model(dtype, head_dim=head_dim or (64 if dtype == torch.float16 else 128))
     model.graph(graph)
     g = torch.Generator(device=DEV).manual_seed(3)
     rnd = lambda *s: torch.randint(1, 512, s, device=DEV, generator=g)

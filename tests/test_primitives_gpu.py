@@ -17,7 +17,7 @@ def _rand(rng, shape, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("b,sq,sk,hq,hkv,causal", [
     (1, 1, 1, 4, 4, False),          # single key
     (2, 5, 37, 8, 2, False),         # GQA, ragged tile tail
@@ -81,7 +81,7 @@ def test_flash_attention_varlen(dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("b,nq,mk,hq,hkv,lens", [
     (4, 1, 16, 8, 8, [5, 16, 3, 1]),
     (3, 1, 300, 8, 1, [300, 1, 77]),     # g = 8 rows per kv head; few units -> in-workgroup key split
