@@ -11,12 +11,16 @@ from tests.gpu_util import case_to_device, rdiff
 from tests.test_fuzz_gpu import _draw, check_fuzz
 from hydragen_amd.attention import hydragen_attention
 
-ap = argparse.ArgumentParser(); ap.add_argument("--first", type=int, default=1000); ap.add_argument("--count", type=int, default=500)
+ap = argparse.ArgumentParser(); ap.add_argument("--first", type=int, default=1000); ap.add_argument("--count", type=int, default=500); ap.add_argument("--dim", type=int, default=0, help="force this head dim (e.g. 256)"); ap.add_argument("--two-stream", action="store_true"); ap.add_argument("--f32-partials", action="store_true")
 a = ap.parse_args()
 import numpy as np
+from hydragen_amd import attention as A
+if a.two_stream: A.set_two_stream('on')
+if a.f32_partials: A.set_f32_partials(True)
 bad = 0; worst = {"f16": 0.0, "bf16": 0.0}; worst_l2 = {"f16": 0.0, "bf16": 0.0}; worst_abs = {"f16": 0.0, "bf16": 0.0}
 for seed in range(a.first, a.first + a.count):
     kw, prefill = _draw(seed)
+    if a.dim: kw['dim'] = a.dim
     case = make_case(**kw)
     if prefill: case["seq_lens"] = None
     out = hydragen_attention(**case_to_device(case)); torch.cuda.synchronize()
