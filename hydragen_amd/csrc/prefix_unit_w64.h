@@ -66,366 +66,68 @@ __device__ __forceinline__ void dma_wait_w() { asm volatile("s_waitcnt vmcnt(%0)
 // a[128 + 4 I : 131 + 4 I] (a[128:191]); scores / P / K / V fragments stay in compiler-allocated VGPRs, where the VALU
 // works on them.  (Given 512 registers and MFMA builtins, or asm operands with register-class or even physical-register
 // constraints, hipcc routes scores and spills through AGPRs and migrates accumulators between the files across
-// iterations: 4-9 extra v_accvgpr_* per MFMA, scratch traffic and a vmcnt(0) inside the loop.)  The clobber lists make
+// iterations: 4-9 extra v_accvgpr_* per MFMA, scratch traffic and a vmcnt(0) inside the loop.)  claim_agprs() makes
 // the kernel descriptor allocate the registers; tests/test_build_quality.py asserts that no compiler-generated
 // instruction names an AGPR (the kernel has no spills, so hipcc has no use for them).
 // Hazards hipcc does not see (cdna_hip_programming.md 5.7): a score block is read by the VALU an iteration after the
 // MFMAs that wrote it were issued; P is consumed an iteration after the VALU packed it; every VALU access to an
 // accumulator (cold rescale, epilogue) is preceded by acc_drain(); v_accvgpr_write -> MFMA is padded inside the asm.
+// The register NUMBERS are assembler expressions of a template constant (`a[%2:%3]`, `a[%0+\r]` inside .irp): one generic
+// definition serves the 8 O blocks and the 16 Q fragments.  These statements carry no clobber lists; claim_agprs()
+// below names a[0:191] once per unit, which is what sizes the kernel descriptor's accumulator file.
+#define HYD_A10(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
+__device__ __forceinline__ void claim_agprs() {
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
+                 HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), HYD_A10(9), HYD_A10(10), HYD_A10(11), HYD_A10(12), HYD_A10(13),
+                 HYD_A10(14), HYD_A10(15), HYD_A10(16), HYD_A10(17), HYD_A10(18), "a190", "a191");
+}
+#undef HYD_A10
+#define HYD_IRP16 ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\t"
+
 template <int I>
-struct OAcc;
+struct OAcc {  // O block I = qb * NDB + db: a[16 I : 16 I + 15]
+    static constexpr int R0 = 16 * I;
+    template <bool BF>
+    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
+        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(R0), "n"(R0 + 15));
+        else asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(R0), "n"(R0 + 15));
+    }
+    static __device__ __forceinline__ void zero() {
+        asm volatile(HYD_IRP16 "v_accvgpr_write_b32 a[%0+\\r], 0\n\t.endr\n\ts_nop 1" ::"n"(R0));
+    }
+    static __device__ __forceinline__ void scale(float f) {
+        float t;
+        asm volatile(HYD_IRP16 "v_accvgpr_read_b32 %0, a[%2+\\r]\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a[%2+\\r], %0\n\t.endr\n\ts_nop 1"
+                     : "=&v"(t)
+                     : "v"(f), "n"(R0));
+    }
+    static __device__ __forceinline__ void read(float (&x)[16]) {
+        asm volatile("v_accvgpr_read_b32 %0, a[%16]\n\tv_accvgpr_read_b32 %1, a[%16+1]\n\tv_accvgpr_read_b32 %2, a[%16+2]\n\t"
+                     "v_accvgpr_read_b32 %3, a[%16+3]\n\tv_accvgpr_read_b32 %4, a[%16+4]\n\tv_accvgpr_read_b32 %5, a[%16+5]\n\t"
+                     "v_accvgpr_read_b32 %6, a[%16+6]\n\tv_accvgpr_read_b32 %7, a[%16+7]\n\tv_accvgpr_read_b32 %8, a[%16+8]\n\t"
+                     "v_accvgpr_read_b32 %9, a[%16+9]\n\tv_accvgpr_read_b32 %10, a[%16+10]\n\tv_accvgpr_read_b32 %11, a[%16+11]\n\t"
+                     "v_accvgpr_read_b32 %12, a[%16+12]\n\tv_accvgpr_read_b32 %13, a[%16+13]\n\tv_accvgpr_read_b32 %14, a[%16+14]\n\t"
+                     "v_accvgpr_read_b32 %15, a[%16+15]"
+                     : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]),
+                       "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15])
+                     : "n"(R0));
+    }
+};
+#undef HYD_IRP16
+
 template <int I>
-struct QFrag;
-template <>
-struct OAcc<0> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"v"(a), "v"(b) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[0:15], %0, %1, a[0:15]" ::"v"(a), "v"(b) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\ts_nop 1" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a0, %0\n\tv_accvgpr_read_b32 %0, a1\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a1, %0\n\tv_accvgpr_read_b32 %0, a2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a2, %0\n\tv_accvgpr_read_b32 %0, a3\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a3, %0\n\tv_accvgpr_read_b32 %0, a4\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a4, %0\n\tv_accvgpr_read_b32 %0, a5\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a5, %0\n\tv_accvgpr_read_b32 %0, a6\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a6, %0\n\tv_accvgpr_read_b32 %0, a7\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a7, %0\n\tv_accvgpr_read_b32 %0, a8\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a8, %0\n\tv_accvgpr_read_b32 %0, a9\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a9, %0\n\tv_accvgpr_read_b32 %0, a10\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a10, %0\n\tv_accvgpr_read_b32 %0, a11\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a11, %0\n\tv_accvgpr_read_b32 %0, a12\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a12, %0\n\tv_accvgpr_read_b32 %0, a13\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a13, %0\n\tv_accvgpr_read_b32 %0, a14\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a14, %0\n\tv_accvgpr_read_b32 %0, a15\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a15, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<1> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"v"(a), "v"(b) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[16:31], %0, %1, a[16:31]" ::"v"(a), "v"(b) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\ts_nop 1" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a16, %0\n\tv_accvgpr_read_b32 %0, a17\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a17, %0\n\tv_accvgpr_read_b32 %0, a18\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a18, %0\n\tv_accvgpr_read_b32 %0, a19\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a19, %0\n\tv_accvgpr_read_b32 %0, a20\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a20, %0\n\tv_accvgpr_read_b32 %0, a21\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a21, %0\n\tv_accvgpr_read_b32 %0, a22\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a22, %0\n\tv_accvgpr_read_b32 %0, a23\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a23, %0\n\tv_accvgpr_read_b32 %0, a24\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a24, %0\n\tv_accvgpr_read_b32 %0, a25\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a25, %0\n\tv_accvgpr_read_b32 %0, a26\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a26, %0\n\tv_accvgpr_read_b32 %0, a27\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a27, %0\n\tv_accvgpr_read_b32 %0, a28\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a28, %0\n\tv_accvgpr_read_b32 %0, a29\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a29, %0\n\tv_accvgpr_read_b32 %0, a30\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a30, %0\n\tv_accvgpr_read_b32 %0, a31\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a31, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<2> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"v"(a), "v"(b) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[32:47], %0, %1, a[32:47]" ::"v"(a), "v"(b) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\ts_nop 1" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a32, %0\n\tv_accvgpr_read_b32 %0, a33\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a33, %0\n\tv_accvgpr_read_b32 %0, a34\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a34, %0\n\tv_accvgpr_read_b32 %0, a35\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a35, %0\n\tv_accvgpr_read_b32 %0, a36\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a36, %0\n\tv_accvgpr_read_b32 %0, a37\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a37, %0\n\tv_accvgpr_read_b32 %0, a38\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a38, %0\n\tv_accvgpr_read_b32 %0, a39\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a39, %0\n\tv_accvgpr_read_b32 %0, a40\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a40, %0\n\tv_accvgpr_read_b32 %0, a41\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a41, %0\n\tv_accvgpr_read_b32 %0, a42\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a42, %0\n\tv_accvgpr_read_b32 %0, a43\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a43, %0\n\tv_accvgpr_read_b32 %0, a44\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a44, %0\n\tv_accvgpr_read_b32 %0, a45\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a45, %0\n\tv_accvgpr_read_b32 %0, a46\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a46, %0\n\tv_accvgpr_read_b32 %0, a47\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a47, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<3> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"v"(a), "v"(b) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[48:63], %0, %1, a[48:63]" ::"v"(a), "v"(b) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\ts_nop 1" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a48, %0\n\tv_accvgpr_read_b32 %0, a49\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a49, %0\n\tv_accvgpr_read_b32 %0, a50\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a50, %0\n\tv_accvgpr_read_b32 %0, a51\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a51, %0\n\tv_accvgpr_read_b32 %0, a52\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a52, %0\n\tv_accvgpr_read_b32 %0, a53\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a53, %0\n\tv_accvgpr_read_b32 %0, a54\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a54, %0\n\tv_accvgpr_read_b32 %0, a55\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a55, %0\n\tv_accvgpr_read_b32 %0, a56\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a56, %0\n\tv_accvgpr_read_b32 %0, a57\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a57, %0\n\tv_accvgpr_read_b32 %0, a58\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a58, %0\n\tv_accvgpr_read_b32 %0, a59\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a59, %0\n\tv_accvgpr_read_b32 %0, a60\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a60, %0\n\tv_accvgpr_read_b32 %0, a61\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a61, %0\n\tv_accvgpr_read_b32 %0, a62\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a62, %0\n\tv_accvgpr_read_b32 %0, a63\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a63, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\tv_accvgpr_read_b32 %8, a56\n\tv_accvgpr_read_b32 %9, a57\n\tv_accvgpr_read_b32 %10, a58\n\tv_accvgpr_read_b32 %11, a59\n\tv_accvgpr_read_b32 %12, a60\n\tv_accvgpr_read_b32 %13, a61\n\tv_accvgpr_read_b32 %14, a62\n\tv_accvgpr_read_b32 %15, a63" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<4> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" ::"v"(a), "v"(b) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[64:79], %0, %1, a[64:79]" ::"v"(a), "v"(b) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\ts_nop 1" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a64, %0\n\tv_accvgpr_read_b32 %0, a65\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a65, %0\n\tv_accvgpr_read_b32 %0, a66\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a66, %0\n\tv_accvgpr_read_b32 %0, a67\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a67, %0\n\tv_accvgpr_read_b32 %0, a68\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a68, %0\n\tv_accvgpr_read_b32 %0, a69\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a69, %0\n\tv_accvgpr_read_b32 %0, a70\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a70, %0\n\tv_accvgpr_read_b32 %0, a71\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a71, %0\n\tv_accvgpr_read_b32 %0, a72\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a72, %0\n\tv_accvgpr_read_b32 %0, a73\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a73, %0\n\tv_accvgpr_read_b32 %0, a74\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a74, %0\n\tv_accvgpr_read_b32 %0, a75\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a75, %0\n\tv_accvgpr_read_b32 %0, a76\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a76, %0\n\tv_accvgpr_read_b32 %0, a77\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a77, %0\n\tv_accvgpr_read_b32 %0, a78\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a78, %0\n\tv_accvgpr_read_b32 %0, a79\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a79, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\tv_accvgpr_read_b32 %8, a72\n\tv_accvgpr_read_b32 %9, a73\n\tv_accvgpr_read_b32 %10, a74\n\tv_accvgpr_read_b32 %11, a75\n\tv_accvgpr_read_b32 %12, a76\n\tv_accvgpr_read_b32 %13, a77\n\tv_accvgpr_read_b32 %14, a78\n\tv_accvgpr_read_b32 %15, a79" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<5> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" ::"v"(a), "v"(b) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[80:95], %0, %1, a[80:95]" ::"v"(a), "v"(b) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\ts_nop 1" ::: "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a80, %0\n\tv_accvgpr_read_b32 %0, a81\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a81, %0\n\tv_accvgpr_read_b32 %0, a82\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a82, %0\n\tv_accvgpr_read_b32 %0, a83\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a83, %0\n\tv_accvgpr_read_b32 %0, a84\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a84, %0\n\tv_accvgpr_read_b32 %0, a85\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a85, %0\n\tv_accvgpr_read_b32 %0, a86\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a86, %0\n\tv_accvgpr_read_b32 %0, a87\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a87, %0\n\tv_accvgpr_read_b32 %0, a88\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a88, %0\n\tv_accvgpr_read_b32 %0, a89\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a89, %0\n\tv_accvgpr_read_b32 %0, a90\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a90, %0\n\tv_accvgpr_read_b32 %0, a91\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a91, %0\n\tv_accvgpr_read_b32 %0, a92\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a92, %0\n\tv_accvgpr_read_b32 %0, a93\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a93, %0\n\tv_accvgpr_read_b32 %0, a94\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a94, %0\n\tv_accvgpr_read_b32 %0, a95\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a95, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\tv_accvgpr_read_b32 %8, a88\n\tv_accvgpr_read_b32 %9, a89\n\tv_accvgpr_read_b32 %10, a90\n\tv_accvgpr_read_b32 %11, a91\n\tv_accvgpr_read_b32 %12, a92\n\tv_accvgpr_read_b32 %13, a93\n\tv_accvgpr_read_b32 %14, a94\n\tv_accvgpr_read_b32 %15, a95" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<6> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" ::"v"(a), "v"(b) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[96:111], %0, %1, a[96:111]" ::"v"(a), "v"(b) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\ts_nop 1" ::: "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a96, %0\n\tv_accvgpr_read_b32 %0, a97\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a97, %0\n\tv_accvgpr_read_b32 %0, a98\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a98, %0\n\tv_accvgpr_read_b32 %0, a99\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a99, %0\n\tv_accvgpr_read_b32 %0, a100\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a100, %0\n\tv_accvgpr_read_b32 %0, a101\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a101, %0\n\tv_accvgpr_read_b32 %0, a102\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a102, %0\n\tv_accvgpr_read_b32 %0, a103\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a103, %0\n\tv_accvgpr_read_b32 %0, a104\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a104, %0\n\tv_accvgpr_read_b32 %0, a105\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a105, %0\n\tv_accvgpr_read_b32 %0, a106\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a106, %0\n\tv_accvgpr_read_b32 %0, a107\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a107, %0\n\tv_accvgpr_read_b32 %0, a108\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a108, %0\n\tv_accvgpr_read_b32 %0, a109\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a109, %0\n\tv_accvgpr_read_b32 %0, a110\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a110, %0\n\tv_accvgpr_read_b32 %0, a111\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a111, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\tv_accvgpr_read_b32 %8, a104\n\tv_accvgpr_read_b32 %9, a105\n\tv_accvgpr_read_b32 %10, a106\n\tv_accvgpr_read_b32 %11, a107\n\tv_accvgpr_read_b32 %12, a108\n\tv_accvgpr_read_b32 %13, a109\n\tv_accvgpr_read_b32 %14, a110\n\tv_accvgpr_read_b32 %15, a111" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct OAcc<7> {
-    template <bool BF>
-    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" ::"v"(a), "v"(b) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-        else asm volatile("v_mfma_f32_32x32x16_f16 a[112:127], %0, %1, a[112:127]" ::"v"(a), "v"(b) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    }
-    static __device__ __forceinline__ void zero() { asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0\n\ts_nop 1" ::: "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); }
-    static __device__ __forceinline__ void scale(float f) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a112, %0\n\tv_accvgpr_read_b32 %0, a113\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a113, %0\n\tv_accvgpr_read_b32 %0, a114\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a114, %0\n\tv_accvgpr_read_b32 %0, a115\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a115, %0\n\tv_accvgpr_read_b32 %0, a116\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a116, %0\n\tv_accvgpr_read_b32 %0, a117\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a117, %0\n\tv_accvgpr_read_b32 %0, a118\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a118, %0\n\tv_accvgpr_read_b32 %0, a119\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a119, %0\n\tv_accvgpr_read_b32 %0, a120\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a120, %0\n\tv_accvgpr_read_b32 %0, a121\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a121, %0\n\tv_accvgpr_read_b32 %0, a122\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a122, %0\n\tv_accvgpr_read_b32 %0, a123\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a123, %0\n\tv_accvgpr_read_b32 %0, a124\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a124, %0\n\tv_accvgpr_read_b32 %0, a125\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a125, %0\n\tv_accvgpr_read_b32 %0, a126\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a126, %0\n\tv_accvgpr_read_b32 %0, a127\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a127, %0\n\ts_nop 1" : "=&v"(t) : "v"(f) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
-    }
-    static __device__ __forceinline__ void read(float (&x)[16]) {
-        asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a120\n\tv_accvgpr_read_b32 %9, a121\n\tv_accvgpr_read_b32 %10, a122\n\tv_accvgpr_read_b32 %11, a123\n\tv_accvgpr_read_b32 %12, a124\n\tv_accvgpr_read_b32 %13, a125\n\tv_accvgpr_read_b32 %14, a126\n\tv_accvgpr_read_b32 %15, a127" : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]), "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15]));
-    }
-};
-template <>
-struct QFrag<0> {
+struct QFrag {  // Q fragment I = qb * NC + c: a[128 + 4 I : 131 + 4 I]
+    static constexpr int R0 = 128 + 4 * I;
     template <int OFF>
     static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[128:131], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a128", "a129", "a130", "a131");
+        asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(p), "n"(R0), "n"(R0 + 3), "n"(OFF) : "memory");
     }
     template <bool BF, bool FIRST>
     static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[128:131], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[128:131], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[128:131], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[128:131], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<1> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[132:135], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a132", "a133", "a134", "a135");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[132:135], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[132:135], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[132:135], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[132:135], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<2> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[136:139], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a136", "a137", "a138", "a139");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[136:139], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[136:139], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[136:139], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[136:139], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<3> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[140:143], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a140", "a141", "a142", "a143");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[140:143], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[140:143], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[140:143], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[140:143], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<4> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[144:147], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a144", "a145", "a146", "a147");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[144:147], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[144:147], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[144:147], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[144:147], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<5> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[148:151], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a148", "a149", "a150", "a151");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[148:151], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[148:151], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[148:151], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[148:151], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<6> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[152:155], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a152", "a153", "a154", "a155");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[152:155], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[152:155], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[152:155], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[152:155], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<7> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[156:159], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a156", "a157", "a158", "a159");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[156:159], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[156:159], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[156:159], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[156:159], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<8> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[160:163], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a160", "a161", "a162", "a163");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[160:163], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[160:163], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[160:163], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[160:163], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<9> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[164:167], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a164", "a165", "a166", "a167");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[164:167], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[164:167], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[164:167], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[164:167], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<10> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[168:171], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a168", "a169", "a170", "a171");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[168:171], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[168:171], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[168:171], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[168:171], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<11> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[172:175], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a172", "a173", "a174", "a175");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[172:175], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[172:175], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[172:175], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[172:175], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<12> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[176:179], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a176", "a177", "a178", "a179");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[176:179], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[176:179], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[176:179], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[176:179], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<13> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[180:183], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a180", "a181", "a182", "a183");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[180:183], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[180:183], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[180:183], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[180:183], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<14> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[184:187], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a184", "a185", "a186", "a187");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[184:187], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[184:187], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[184:187], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[184:187], %0" : "+v"(s) : "v"(a));
-    }
-};
-template <>
-struct QFrag<15> {
-    template <int OFF>
-    static __device__ __forceinline__ void load(const void* p) {
-        asm volatile("global_load_dwordx4 a[188:191], %0, off offset:%1" ::"v"(p), "i"(OFF) : "memory", "a188", "a189", "a190", "a191");
-    }
-    template <bool BF, bool FIRST>
-    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
-        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[188:191], 0" : "=&v"(s) : "v"(a));
-        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[188:191], %0" : "+v"(s) : "v"(a));
-        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[188:191], 0" : "=&v"(s) : "v"(a));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[188:191], %0" : "+v"(s) : "v"(a));
+        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], 0" : "=&v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], 0" : "=&v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], %0" : "+v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
     }
 };
 // every MFMA issued so far has written its result (8-pass XDL: 18 wait states cover any reader)
@@ -465,6 +167,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, int QB = (D > 128 ? 1 : 2)>
 __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
+    claim_agprs();
     static_assert(QB == 1 || QB == 2, "query blocks per wave");
     static_assert(D <= 128 || (QB == 1 && KG == 1), "D = 256 runs one query block per wave and unsplit key tiles");
     constexpr int WROWS = 32 * QB;       // query rows per wave

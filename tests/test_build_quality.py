@@ -77,7 +77,8 @@ def test_prefix_kernel_owns_its_accumulator_registers():
     assert not bad, bad[:5]
     counts = [int(x) for x in re.findall(r"\.agpr_count:\s+(\d+)", out)]
     assert counts and min(counts) >= 160, counts
-    assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and "a[128:131]" in out
+    # (register numbers are assembler expressions of template constants; hipcc prints the larger ones in hex)
+    assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and re.search(r"a\[(128|0x80):(131|0x83)\]", out)
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
