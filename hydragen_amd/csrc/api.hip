@@ -315,6 +315,8 @@ int run_suffix(const hyd_suffix_params* p, const hyd_partial* parts, int n_parts
         }
     }
     a.n_partials = n;
+    a.n_pre = 0;
+    while (a.n_pre < 2 && a.n_pre < n && !a.partials[a.n_pre].is_f32) ++a.n_pre;
     if ((int64_t)p->kv_len * p->k_tok_stride * 2 >= (1ll << 31) || (int64_t)p->kv_len * p->v_tok_stride * 2 >= (1ll << 31))
         return fail(HYD_ERR_UNSUPPORTED, "unique K/V of one sequence spans >= 2 GiB (32-bit in-sequence offsets)");
     if (p->Hkv > 4 * 65535 || a.rows > 8 * 65535) return fail(HYD_ERR_UNSUPPORTED, "too many kv heads / query rows for the suffix grid");

@@ -51,7 +51,7 @@ struct SuffixArgs {
     int32_t n_partials;
     float scale_log2e;
     int32_t packed;  // shapes allow the lane-group path for short sequences (set by launch_suffix)
-    int32_t pad_;
+    int32_t n_pre;   // leading 16-bit partials the kernels fetch under the K/V stream (0..2, set by run_suffix)
     PartialDev partials[kMaxCombine];
 };
 

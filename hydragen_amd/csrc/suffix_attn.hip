@@ -34,7 +34,7 @@ namespace hyd {
 // one-unit-per-wave path streams 2-4 % faster -- more loads in flight -- so the choice is made per sequence at RUN time
 // from its length, inside the one kernel the shapes select: capture-safe, no device read on the host).
 constexpr int kPackedMaxLen = 12;
-template <typename T, int D>
+template <typename T, int D, int NPRE>
 __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, int ygroup, int len) {
     using TR = Traits<T>;
     constexpr int LPK = D / 8;     // lanes per unit
@@ -51,14 +51,10 @@ __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, i
 
     const int64_t ridx = (int64_t)b * a.Hq + hkc;  // nq == 1, g == 1: [B, 1, Hq]
     const u32x4 qp = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.q) + ridx * D + sub * 8);
-    // the first partial (the usual single prefix level), fetched under the K/V stream
-    const bool pre0 = a.n_partials > 0 && !a.partials[0].is_f32;
-    float pl0 = 0.f;
-    u32x4 po0 = {0u, 0u, 0u, 0u};
-    if (pre0) {
-        pl0 = a.partials[0].lse[ridx];
-        po0 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.partials[0].out) + ridx * D + sub * 8);
-    }
+    // the first 16-bit partials (the usual single prefix level; a second level), fetched under the K/V stream
+    const int npre = min(n_prefetched(a), NPRE);
+    PrePartials<NPRE> pp;
+    prefetch_partials(a, npre, ridx, sub, D, pp);
 
     // wave-uniform sequence base (scalar registers) + per-lane 32-bit byte offset (head, dims) -> SADDR-form loads
     const gchar_p kbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs));
@@ -116,10 +112,12 @@ __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, i
     for (; t + U <= len; t += U) chunk(std::integral_constant<int, U>{}, t);
     for (; t < len; ++t) chunk(std::integral_constant<int, 1>{}, t);
 
-    if (hvalid) finish_row<T, D, 2>(a, ridx, sub, m, l, acc, pre0, pl0, po0);
+    if (hvalid) finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
 }
 
-template <typename T, int D, int R, int WPU>
+// NPRE: 16-bit partials fetched under the K/V stream (suffix_common.h); 2 is instantiated for the decode shape only
+// (R = 1, one wave per unit) and launched when the call has two such partials (a two-level hierarchy).
+template <typename T, int D, int R, int WPU, int NPRE = 1>
 __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int LPK = D / 8;    // lanes per key row
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
         // short sequence and a packable shape (a.packed, shapes only): the first of every 4 workgroups of this
         // sequence serves the 16 (D = 128) kv heads of all four with the lane-group layout, the other three leave
         if (a.packed && len <= kPackedMaxLen) {
-            if ((blockIdx.y & 3) == 0) suffix_packed_body<T, D>(a, b, blockIdx.y >> 2, len);
+            if ((blockIdx.y & 3) == 0) suffix_packed_body<T, D, NPRE>(a, b, blockIdx.y >> 2, len);
             return;
         }
     }
@@ -169,24 +167,20 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
             qp[r] = z;
         }
     }
-    // ---- prefetch the first partial (the usual single prefix level) for the row this lane group will
-    // finish in the epilogue, so its HBM latency overlaps the K/V stream instead of following it -----
+    // ---- prefetch the first 16-bit partials (the usual single prefix level; a second level) for the rows this lane
+    // group will finish in the epilogue, so their HBM latency overlaps the K/V stream instead of following it -----
     constexpr int RPG = (R + KPI - 1) / KPI;  // epilogue rows per lane group
-    float pl0[RPG];
-    u32x4 po0[RPG];
-    const bool pre0 = a.n_partials > 0 && !a.partials[0].is_f32;
+    PrePartials<NPRE> pp[RPG];
+    const int npre = min(n_prefetched(a), NPRE);
 #pragma unroll
     for (int j = 0; j < RPG; ++j) {
         const int r = ks + j * KPI;
         const int row = row0 + r;
-        pl0[j] = 0.f;
-        po0[j] = u32x4{0u, 0u, 0u, 0u};
-        if (pre0 && r < R && row < a.rows) {
-            const int iq = a.nq == 1 ? 0 : row / a.g, gq = a.nq == 1 ? row : row % a.g;
-            const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;
-            pl0[j] = a.partials[0].lse[ridx];
-            po0[j] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.partials[0].out) + ridx * D + sub * 8);
-        }
+        const bool live = r < R && row < a.rows;
+        const int rowc = live ? row : 0;
+        const int iq = a.nq == 1 ? 0 : rowc / a.g, gq = a.nq == 1 ? rowc : rowc % a.g;
+        const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;
+        prefetch_partials(a, live ? npre : 0, ridx, sub, D, pp[j]);
     }
 
     // wave-uniform unit base (scalar registers) + 32-bit per-lane byte offsets -> SADDR-form loads
@@ -312,7 +306,7 @@ __global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(cons
         if (row >= a.rows || ks != (r % KPI)) continue;
         const int iq = a.nq == 1 ? 0 : row / a.g, gq = a.nq == 1 ? row : row % a.g;
         const int64_t ridx = ((int64_t)b * a.nq + iq) * a.Hq + hk * a.g + gq;  // [B, nq, Hq]
-        finish_row<T, D>(a, ridx, sub, m[r], l[r], acc[r], pre0, pl0[r / KPI], po0[r / KPI]);
+        finish_row<T, D, 4, NPRE>(a, ridx, sub, m[r], l[r], acc[r], npre, pp[r / KPI]);
     }
 }
 
@@ -334,6 +328,12 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
             return (int)hipGetLastError();
         }
 #endif
+        if constexpr (R == 1) {
+            if (a.n_pre == 2) {
+                hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 2>), grid, dim3(256), 0, s, a);
+                return (int)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();

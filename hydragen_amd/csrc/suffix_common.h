@@ -38,11 +38,35 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float (&acc)[8],
 }
 
 // Epilogue of one output row (8 dims per lane, the D/8 lanes of a row call it together): normalise the suffix pass's
-// (m, l, acc), merge with the prefix partials (attention.py:21-43 semantics, N partials) and store.  Partial 0 may
-// already sit in registers (pre0: prefetched under the K/V stream).
-template <typename T, int D, int NBATCH = 4>
+// (m, l, acc), merge with the prefix partials (attention.py:21-43 semantics, N partials) and store.  The first npre
+// partials already sit in registers (PrePartials: prefetched under the K/V stream).
+// 16-bit partials fetched under the K/V stream: the first NPRE of a call (consecutive ones from partial 0).  One
+// covers the usual single prefix level; the second is a two-level hierarchy's (BASELINE config 4): left to the epilogue,
+// its two dependent round trips (LSE, then the row) cost 17 us of a 113 us suffix pass there.
+// The kernels are instantiated for NPRE = 1 and 2 and picked by a.n_pre (counted on the host): carrying the second slot
+// through the single-level call costs it 7 % at suffix 16 (registers and issue slots of a ~2 us wave).
+template <int NPRE>
+struct PrePartials {
+    float lse[NPRE];
+    u32x4 out[NPRE];
+};
+__device__ __forceinline__ int n_prefetched(const SuffixArgs& a) { return a.n_pre; }
+template <int NPRE>
+__device__ __forceinline__ void prefetch_partials(const SuffixArgs& a, int npre, int64_t ridx, int sub, int D, PrePartials<NPRE>& pp) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+        pp.lse[i] = 0.f;
+        pp.out[i] = u32x4{0u, 0u, 0u, 0u};
+        if (i < npre) {
+            pp.lse[i] = a.partials[i].lse[ridx];
+            pp.out[i] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.partials[i].out) + ridx * D + sub * 8);
+        }
+    }
+}
+
+template <typename T, int D, int NBATCH = 4, int NPRE = 1>
 __device__ __forceinline__ void finish_row(const SuffixArgs& a, int64_t ridx, int sub, float m, float l, const float (&acc)[8],
-                                           bool pre0, float l0, const u32x4& po0) {
+                                           int npre, const PrePartials<NPRE>& pp) {
     using TR = Traits<T>;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     const float lse_s = l > 0.f ? m * kLn2 + __logf(l) : -INFINITY;
@@ -52,11 +76,14 @@ __device__ __forceinline__ void finish_row(const SuffixArgs& a, int64_t ridx, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) num[j] = acc[j] * inv;
     } else {
-        const int i0 = pre0 ? 1 : 0;  // partial 0 already sits in registers
+        const int i0 = npre;  // partials [0, npre) already sit in registers
         // The remaining partials (split-KV slices, further levels) are read NBATCH at a time with clamped indices,
         // so that a batch's loads are all in flight together instead of one memory latency per partial.
         const int np = a.n_partials;
-        float M = pre0 ? fmaxf(lse_s, l0) : lse_s;
+        float M = lse_s;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i)
+            if (i < npre) M = fmaxf(M, pp.lse[i]);
         for (int i = i0; i < np; i += NBATCH) {
             float lv[NBATCH];
 #pragma unroll
@@ -69,13 +96,16 @@ __device__ __forceinline__ void finish_row(const SuffixArgs& a, int64_t ridx, in
         float den = ws;
 #pragma unroll
         for (int j = 0; j < 8; ++j) num[j] = acc[j] * (inv * ws);
-        if (pre0) {
-            const float w = __expf(l0 - Ms);
-            den += w;
-            float pv[8];
-            widen8<T>(po0, pv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
+        for (int i = 0; i < NPRE; ++i) {
+            if (i < npre) {
+                const float w = __expf(pp.lse[i] - Ms);
+                den += w;
+                float pv[8];
+                widen8<T>(pp.out[i], pv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) num[j] = __builtin_fmaf(w, pv[j], num[j]);
+            }
         }
         for (int i = i0; i < np;) {
             // a batch = up to NBATCH consecutive partials of the same element type (slices of one level are adjacent)

@@ -7,5 +7,5 @@ from hydragen_amd import _lib
 if "r2" in os.environ.get("HYDRAGEN_HIP_LIB", ""):
     _lib.ABI_VERSION = 201
     _lib.EXPORTS.pop("hyd_decode_two_stream_ok")
-sys.argv = ["kbench.py", "prefix"] + sys.argv[1:]
+sys.argv = ["kbench.py"] + (sys.argv[1:] if len(sys.argv) > 1 and sys.argv[1] in ("prefix", "suffix", "fused") else ["prefix"] + sys.argv[1:])
 runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tools", "kbench.py"), run_name="__main__")

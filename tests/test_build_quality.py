@@ -16,7 +16,7 @@ LIMITS = {
     "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512)],   # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs)
     # 2 waves / SIMD (two 8-KiB V tiles per wave bound the occupancy anyway); the count includes the 64 AGPRs of the K sets
     "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256)],
-    "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1E", 80)],  # MHA decode: 6 waves / SIMD
+    "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1ELi\dE", 80)],  # <T, D, R = 1, WPU = 1, NPRE>, MHA decode: 6 waves / SIMD
     "combine.hip": [(r"combine", 128)],
     "rope_append.hip": [(r"rope_append", 128)],
 }
