@@ -173,6 +173,10 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->vgrid = pl.grid;
     a->lse_q_stride = pl.qpg;
     a->scale_log2e = scale_log2e_of(p->softmax_scale, p->D);
+    a->div_row_blocks = make_fastdiv((uint32_t)pl.row_blocks);
+    a->div_nsplit = make_fastdiv((uint32_t)pl.nsplit);
+    a->div_hkv = make_fastdiv((uint32_t)p->Hkv);
+    a->div_g = make_fastdiv((uint32_t)pl.g);
     a->dbg = dev_switch("HYD_DBG");  // timing-ablation kernel variants; always 0 in product builds
 }
 

@@ -7,6 +7,21 @@ namespace hyd {
 constexpr int kMaxCombine = 64;  // (f32_mask of CombineArgs is 64 bits wide)
 constexpr int HYD_MIXED = 3;     // CombineArgs.dtype_in only: the partials are a mix of fp32 and the 16-bit output dtype  // partials one combine launch / one suffix epilogue can merge
 
+// Division by a launch constant without a divide on the device (Granlund & Montgomery, round-up method, exact for every
+// 32-bit n and d >= 1): q = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(mul, n).  The host fills it (make_fastdiv).
+struct FastDiv {
+    uint32_t mul;
+    uint32_t sh;  // sh1 | sh2 << 8
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while (l < 32 && (uint64_t(1) << l) < d) ++l;  // ceil(log2 d)
+    FastDiv f;
+    f.mul = (uint32_t)(((uint64_t(1) << 32) * ((uint64_t(1) << l) - d)) / d + 1);
+    f.sh = (l < 1 ? l : 1) | ((l > 1 ? l - 1 : 0) << 8);
+    return f;
+}
+
 struct PrefixArgs {
     const void* q;
     const void* k;
@@ -26,6 +41,7 @@ struct PrefixArgs {
     int32_t wg_rows;  // query rows per workgroup: 128, or 256 (pipelined kernel, D = 128, large row counts)
     int32_t lse_layout, out_f32;
     float scale_log2e;
+    FastDiv div_row_blocks, div_nsplit, div_hkv, div_g;  // the unit / row decode divides by these four
     int32_t dbg;  // 0 in product builds; HYD_ABLATION_BUILD reads HYD_DBG to pick a timing-ablation variant of a prefix kernel
 };
 

@@ -168,6 +168,7 @@ template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, int QB = (D > 128
 __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
     claim_agprs();
+    if constexpr ((ABL & 4096) != 0) asm volatile("s_nop 0");  // development: shifts the whole stream by 4 bytes (code-placement probe)
     static_assert(QB == 1 || QB == 2, "query blocks per wave");
     static_assert(D <= 128 || (QB == 1 && KG == 1), "D = 256 runs one query block per wave and unsplit key tiles");
     constexpr int WROWS = 32 * QB;       // query rows per wave
@@ -203,13 +204,18 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- which (group, kv head, split, row block) ------------------------------------------
+    // (no divide on the device: magic numbers from the host, hyd_kernels.h FastDiv)
+    auto fdiv = [](unsigned n, const FastDiv& f) __attribute__((always_inline)) -> unsigned {
+        const unsigned t = __umulhi(n, f.mul);
+        return (t + ((n - t) >> (f.sh & 0xffu))) >> (f.sh >> 8);
+    };
     const int lin = xcd_remap(vblock, vgrid);
-    const int rb = lin % a.row_blocks;
-    int t_ = lin / a.row_blocks;
-    const int sp = t_ % a.nsplit;
-    t_ /= a.nsplit;
-    const int hk = t_ % a.Hkv;
-    const int gi = t_ / a.Hkv;
+    int t_ = (int)fdiv((unsigned)lin, a.div_row_blocks);
+    const int rb = lin - t_ * a.row_blocks;
+    const int t2_ = (int)fdiv((unsigned)t_, a.div_nsplit);
+    const int sp = t_ - t2_ * a.nsplit;
+    const int gi = (int)fdiv((unsigned)t2_, a.div_hkv);
+    const int hk = t2_ - gi * a.Hkv;
 
     int q_tok0, nqtok, nq_eff;
     if (a.cu_q) {
@@ -261,8 +267,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         const int r = rb * RWG + rw * WROWS + qb * 32 + l31_;
         valid = r < Mrows;
         const int rc = min(r, Mrows - 1);
-        tok = rc / a.g;  // query token inside the group
-        hqv = hk * a.g + rc % a.g;
+        tok = (int)fdiv((unsigned)rc, a.div_g);  // query token inside the group
+        hqv = hk * a.g + (rc - tok * a.g);
         off = ((int64_t)(q_tok0 + tok) * a.Hq + hqv) * D;
     };
     int row_lim[QB];
