@@ -67,3 +67,40 @@ def test_bench_single_gpu_line_is_complete():
     assert abs(res["trials"]["trial0_us_per_step"] - res["ms_per_step"] * 1e3) < 1e-6
     assert set(res["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(res["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "c1_full"}
+
+
+def test_launch_schedule_is_what_a_profiler_sees():
+    """profiles/traffic_latest.json divides the PMC totals by bench.launch_schedule(): 3 eager warm-ups per captured suffix
+    length, the warm-up steps, the timed steps (and the repeats when there are any) -- with the mean suffix of the timed
+    schedule, so per-launch averages of a profile compare with the bench line."""
+    import bench
+
+    ls = bench.launch_schedule(20, 5, 0, 128)
+    assert len(ls) == 3 * 25 + 5 + 20 and abs(sum(ls) / len(ls) - 64.6) < 0.05
+    assert len(bench.launch_schedule(20, 5, 3, 128)) == len(ls) + 60
+    sched = bench.suffix_schedule(20, 128)
+    ev = sorted({i for i in range(10) if i % 4 == 1} | {19 - i for i in range(10) if i % 4 == 1})
+    assert abs(sum(sched[i] for i in ev) / len(ev) - sum(sched) / 20) < 0.2  # event steps: the schedule's mean suffix
+
+
+def test_two_stream_policy_is_shapes_only():
+    """'auto' never looks at device data: capture state + shapes decide (hydragen_amd/attention.py::_want_two_stream)."""
+    import torch
+
+    from hydragen_amd import attention as A
+
+    q = torch.empty(1024, 1, 32, 128, dtype=torch.bfloat16, device="meta")
+    k = torch.empty(1024, 128, 32, 128, dtype=torch.bfloat16, device="meta")
+    sk = torch.empty(1, 2048, 32, 128, dtype=torch.bfloat16, device="meta")
+    args = (q, k, [sk], [None], [False])
+    assert A._two_stream_mode == "off" and not A._want_two_stream(*args, capturing=True)
+    prev = A.set_two_stream("auto")
+    try:
+        assert A._want_two_stream(*args, capturing=True) and not A._want_two_stream(*args, capturing=False)
+        assert not A._want_two_stream(q, k[:, :8], [sk], [None], [False], capturing=True)     # a cache too short to hide a prefix pass
+        assert not A._want_two_stream(q[:4], k[:4], [sk[:, :64]], [None], [False], capturing=True)  # C1-sized: nothing worth hiding
+        assert not A._want_two_stream(q, k, [], [], [], capturing=True)
+        A.set_two_stream("on")
+        assert A._want_two_stream(*args, capturing=False)
+    finally:
+        A.set_two_stream(prev)
