@@ -86,6 +86,30 @@ class RopeParams(C.Structure):
     ]
 
 
+class AddRmsnormParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("residual", C.c_void_p), ("weight", C.c_void_p), ("sum_out", C.c_void_p), ("norm_out", C.c_void_p),
+        ("x_row_stride", C.c_int64), ("residual_row_stride", C.c_int64), ("sum_row_stride", C.c_int64),
+        ("norm_row_stride", C.c_int64), ("rows", C.c_int64), ("n", C.c_int32), ("dtype", C.c_int32), ("eps", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
+class SwigluParams(C.Structure):
+    _fields_ = [
+        ("gate", C.c_void_p), ("up", C.c_void_p), ("out", C.c_void_p),
+        ("gate_row_stride", C.c_int64), ("up_row_stride", C.c_int64), ("out_row_stride", C.c_int64),
+        ("rows", C.c_int64), ("n", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p), ("out", C.c_void_p), ("row_stride", C.c_int64), ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("rows", C.c_int32), ("n", C.c_int32), ("dtype", C.c_int32), ("temperature", C.c_float),
+    ]
+
+
 class AllReduceParams(C.Structure):
     _fields_ = [
         ("blocks", C.POINTER(C.c_void_p)), ("in_", C.c_void_p), ("out", C.c_void_p), ("count", C.c_int64),
@@ -108,6 +132,9 @@ EXPORTS = {
     "hyd_decode_attn_fused": (C.c_int, [C.POINTER(DecodeParams), C.c_void_p]),
     "hyd_decode_two_stream_ok": (C.c_int, [C.POINTER(DecodeParams)]),
     "hyd_rope_append_decode": (C.c_int, [C.POINTER(RopeParams), C.c_void_p]),
+    "hyd_add_rmsnorm": (C.c_int, [C.POINTER(AddRmsnormParams), C.c_void_p]),
+    "hyd_swiglu": (C.c_int, [C.POINTER(SwigluParams), C.c_void_p]),
+    "hyd_sample_tokens": (C.c_int, [C.POINTER(SampleParams), C.c_void_p]),
     "hyd_ipc_get_handle": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hyd_ipc_open_handle": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "hyd_ipc_close_handle": (C.c_int, [C.c_void_p]),
@@ -119,7 +146,7 @@ EXPORTS = {
 }
 
 _lib = None
-ABI_VERSION = 300  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
+ABI_VERSION = 400  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
 
 
 def lib_path() -> Path:

@@ -516,6 +516,69 @@ int hyd_rope_append_decode(const hyd_rope_params* p, void* stream) {
     return rc ? fail(HYD_ERR_LAUNCH, "rope_append kernel launch failed: hip error %d", rc) : HYD_OK;
 }
 
+int hyd_add_rmsnorm(const hyd_add_rmsnorm_params* p, void* stream) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    if (p->dtype != HYD_F16 && p->dtype != HYD_BF16) return fail(HYD_ERR_UNSUPPORTED, "dtype %d (fp16 / bf16)", p->dtype);
+    if (p->rows < 0 || p->rows > 0x7fffffff) return fail(HYD_ERR_BAD_ARG, "rows %lld", (long long)p->rows);
+    if (p->n <= 0 || p->n % 8 != 0 || p->n > 16384) return fail(HYD_ERR_UNSUPPORTED, "n %d: a multiple of 8 up to 16384", p->n);
+    if (!p->x || !p->weight || !p->norm_out) return fail(HYD_ERR_BAD_ARG, "x / weight / norm_out is null");
+    int rc;
+    if ((rc = check_ptr_align(p->x, "x")) || (rc = check_ptr_align(p->weight, "weight")) || (rc = check_ptr_align(p->norm_out, "norm_out")) ||
+        (rc = check_stride8(p->x_row_stride, "x_row_stride")) || (rc = check_stride8(p->norm_row_stride, "norm_row_stride")))
+        return rc;
+    if (p->residual && ((rc = check_ptr_align(p->residual, "residual")) || (rc = check_stride8(p->residual_row_stride, "residual_row_stride"))))
+        return rc;
+    if (p->residual && p->sum_out && ((rc = check_ptr_align(p->sum_out, "sum_out")) || (rc = check_stride8(p->sum_row_stride, "sum_row_stride"))))
+        return rc;
+    NormArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = p->x; a.residual = p->residual; a.weight = p->weight; a.sum_out = p->residual ? p->sum_out : nullptr; a.norm_out = p->norm_out;
+    a.x_rs = p->x_row_stride; a.r_rs = p->residual_row_stride; a.s_rs = p->sum_row_stride; a.o_rs = p->norm_row_stride;
+    a.rows = p->rows; a.n = p->n; a.eps = p->eps;
+    rc = launch_add_rmsnorm(a, p->dtype, static_cast<hipStream_t>(stream));
+    return rc ? fail(HYD_ERR_LAUNCH, "add_rmsnorm kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
+int hyd_swiglu(const hyd_swiglu_params* p, void* stream) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    if (p->dtype != HYD_F16 && p->dtype != HYD_BF16) return fail(HYD_ERR_UNSUPPORTED, "dtype %d (fp16 / bf16)", p->dtype);
+    if (p->rows < 0 || p->n <= 0 || p->n % 8 != 0) return fail(HYD_ERR_UNSUPPORTED, "rows %lld, n %d: n must be a positive multiple of 8", (long long)p->rows, p->n);
+    if (p->rows * (p->n / 8) > 0x7fffffffLL * 256) return fail(HYD_ERR_UNSUPPORTED, "rows x n too large for one launch");
+    if (!p->gate || !p->up || !p->out) return fail(HYD_ERR_BAD_ARG, "gate / up / out is null");
+    int rc;
+    if ((rc = check_ptr_align(p->gate, "gate")) || (rc = check_ptr_align(p->up, "up")) || (rc = check_ptr_align(p->out, "out")) ||
+        (rc = check_stride8(p->gate_row_stride, "gate_row_stride")) || (rc = check_stride8(p->up_row_stride, "up_row_stride")) ||
+        (rc = check_stride8(p->out_row_stride, "out_row_stride")))
+        return rc;
+    SwigluArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gate = p->gate; a.up = p->up; a.out = p->out;
+    a.g_rs = p->gate_row_stride; a.u_rs = p->up_row_stride; a.o_rs = p->out_row_stride;
+    a.rows = p->rows; a.n = p->n;
+    rc = launch_swiglu(a, p->dtype, static_cast<hipStream_t>(stream));
+    return rc ? fail(HYD_ERR_LAUNCH, "swiglu kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
+int hyd_sample_tokens(const hyd_sample_params* p, void* stream) {
+    if (!p) return fail(HYD_ERR_BAD_ARG, "null params");
+    if (p->dtype != HYD_F16 && p->dtype != HYD_BF16 && p->dtype != HYD_F32) return fail(HYD_ERR_UNSUPPORTED, "dtype %d", p->dtype);
+    if (p->rows < 0 || p->n <= 0) return fail(HYD_ERR_BAD_ARG, "rows %d, n %d", p->rows, p->n);
+    if (!p->logits || !p->out) return fail(HYD_ERR_BAD_ARG, "logits / out is null");
+    if (!(p->temperature >= 0.f)) return fail(HYD_ERR_BAD_ARG, "temperature %g must be >= 0", (double)p->temperature);
+    if (p->row_stride < p->n) return fail(HYD_ERR_BAD_ARG, "row_stride %lld < n %d", (long long)p->row_stride, p->n);
+    const int esz = p->dtype == HYD_F32 ? 4 : 2;
+    if ((reinterpret_cast<uintptr_t>(p->logits) & (uintptr_t)(esz - 1)) != 0 || (reinterpret_cast<uintptr_t>(p->out) & 7u) != 0)
+        return fail(HYD_ERR_BAD_ARG, "logits / out is not aligned to its element size");
+    SampleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.logits = p->logits; a.out = p->out; a.row_stride = p->row_stride; a.seed = p->seed; a.offset = p->offset;
+    a.rows = p->rows; a.n = p->n;
+    a.inv_temperature = p->temperature > 0.f ? 1.0f / p->temperature : 0.f;
+    a.vec_ok = ((reinterpret_cast<uintptr_t>(p->logits) & 15u) == 0 && p->row_stride % 8 == 0) ? 1 : 0;
+    const int rc = launch_sample(a, p->dtype, static_cast<hipStream_t>(stream));
+    return rc ? fail(HYD_ERR_LAUNCH, "sample kernel launch failed: hip error %d", rc) : HYD_OK;
+}
+
 // attention.py:273-274: a single shared level and no unique keys -> the prefix result IS the answer
 static bool decode_is_prefix_only(const hyd_decode_params* p) { return p->n_levels == 1 && p->suffix.kv_len == 0; }
 

@@ -102,9 +102,43 @@ struct RopeArgs {
     int32_t B, Hq, Hkv, cache_len, max_pos;
 };
 
+struct NormArgs {  // layer_ops.hip: h = residual + x; normed = RMSNorm(h) * weight
+    const void* x;
+    const void* residual;  // may be null (plain RMSNorm of x)
+    const void* weight;
+    void* sum_out;         // may be null
+    void* norm_out;
+    int64_t x_rs, r_rs, s_rs, o_rs;  // row strides (elements)
+    int64_t rows;
+    int32_t n;
+    float eps;
+};
+
+struct SwigluArgs {  // layer_ops.hip: out = silu(gate) * up
+    const void* gate;
+    const void* up;
+    void* out;
+    int64_t g_rs, u_rs, o_rs;  // row strides (elements)
+    int64_t rows;
+    int32_t n;
+};
+
+struct SampleArgs {  // layer_ops.hip: out[row] ~ softmax(logits[row] / T) (Gumbel-max), or argmax when inv_temperature == 0
+    const void* logits;
+    int64_t* out;
+    int64_t row_stride;  // elements
+    uint64_t seed, offset;
+    int32_t rows, n;
+    float inv_temperature;
+    int32_t vec_ok;      // rows are 16-byte aligned
+};
+
 // launchers (defined next to the kernels); return hipError_t as int
 int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
 int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
+int launch_add_rmsnorm(const NormArgs& a, int dtype, hipStream_t s);
+int launch_swiglu(const SwigluArgs& a, int dtype, hipStream_t s);
+int launch_sample(const SampleArgs& a, int dtype, hipStream_t s);
 int launch_suffix(const SuffixArgs& a, int dtype, int D, hipStream_t s);
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape);
 int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s);

@@ -23,6 +23,7 @@ from typing import List, Optional, Union
 import torch
 from torch import Tensor, nn
 
+from . import layer_ops
 from .attention import hydragen_attention
 from .flash import flash_attention, flash_attention_seqlen
 from .tp import all_reduce_sum, check_collectives
@@ -113,9 +114,11 @@ class LlamaMLP(nn.Module):
         self._gate_up = w = _fused_weight(self._gate_up, (self.gate_proj, self.up_proj))
         if w is not None:
             g, u = nn.functional.linear(x, w).split(self.gate_proj.weight.shape[0], dim=-1)
-            y = self.down_proj(nn.functional.silu(g) * u)
         else:
-            y = self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+            g, u = self.gate_proj(x), self.up_proj(x)
+        # silu(gate) * up: one HIP kernel over the two column halves of the fused GEMM output (the strided silu and the
+        # strided multiply were 15 + 19 us per layer at batch 1024); the torch form on CPU / fp32 / odd widths
+        y = self.down_proj(layer_ops.swiglu(g, u) if layer_ops.supported(g) else nn.functional.silu(g) * u)
         return all_reduce_sum(y) if self.tp_reduce else y
 
 
@@ -443,9 +446,23 @@ class HydragenLlamaModel(nn.Module):
 
     def forward(self, input_ids, position_ids):
         h = self.embed_tokens(input_ids)
-        for layer in self.layers:
-            h = layer(h, position_ids=position_ids)
-        return self.norm(h)
+        layers = list(self.layers)
+        w0 = self.norm.weight
+        if not layers or not layer_ops.supported(h) or w0.dtype != h.dtype:
+            for layer in layers:  # CPU / fp32 / odd widths: the spelled-out layer (llama.py:610-633)
+                h = layer(h, position_ids=position_ids)
+            return self.norm(h)
+        # Same dataflow with every residual add fused into the norm that consumes it (llama.py:615-631: `residual +
+        # hidden_states`, then the next LlamaRMSNorm): one kernel that reads the block output and the residual stream
+        # once and writes the new stream and its normalised form, instead of an add and a norm launch per block.
+        first = layers[0].input_layernorm
+        _, normed = layer_ops.add_rms_norm(h, None, first.weight, first.variance_epsilon)
+        for i, layer in enumerate(layers):
+            post = layer.post_attention_layernorm
+            h, normed = layer_ops.add_rms_norm(layer.self_attn(normed, position_ids), h, post.weight, post.variance_epsilon)
+            nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else self.norm
+            h, normed = layer_ops.add_rms_norm(layer.mlp(normed), h, nxt.weight, nxt.variance_epsilon)
+        return normed
 
 
 @dataclass
@@ -638,7 +655,9 @@ class HydragenLlamaForCausalLM(nn.Module):
             layer.self_attn.kv_cache.repeat_per_completion_cache_for_num_samples(current_size, num_samples)
 
     # ---- forward -------------------------------------------------------------------------------------
-    def forward(self, input_ids, position_ids, seq_lens=None, use_graph=False, full_logits=False):
+    def forward(self, input_ids, position_ids, seq_lens=None, use_graph=False, full_logits=False, raw_logits=False):
+        """Logits in fp32 as the reference returns them (llama.py:1063-1070); raw_logits=True keeps the lm_head's own
+        dtype (the decode loop's fused sampler reads them once, without the fp32 copy)."""
         model = self.graphed_model if use_graph else self.model
         assert model is not None
         hidden = model(input_ids=input_ids, position_ids=position_ids)
@@ -648,7 +667,8 @@ class HydragenLlamaForCausalLM(nn.Module):
             to_lm_head = hidden[torch.arange(hidden.shape[0], device=hidden.device), seq_lens - 1].unsqueeze(1)
         else:
             to_lm_head = hidden[:, -1:]
-        return self.lm_head(to_lm_head).float()
+        logits = self.lm_head(to_lm_head)
+        return logits if raw_logits else logits.float()
 
     def apply_top_p(self, logits, top_p, min_tokens_to_keep=1, filter_value=-float("Inf")):
         sorted_logits, sorted_indices = torch.sort(logits, descending=False)
@@ -660,6 +680,10 @@ class HydragenLlamaForCausalLM(nn.Module):
     def sample_from_logits(self, logits, temperature, num_samples=1, top_p=None):
         if top_p is not None:
             logits = self.apply_top_p(logits, top_p)
+        if logits.is_cuda and logits.ndim == 2 and num_samples == 1 and logits.stride(-1) == 1 and temperature >= 0:
+            # one HIP kernel: argmax(logits / T + Gumbel noise) draws exactly from softmax(logits / T) -- what the softmax +
+            # torch.multinomial chain below draws, in one pass over the logits instead of ~12 launches over [B, vocab]
+            return layer_ops.sample_tokens(logits, temperature)
         if temperature == 0:
             assert logits.ndim == 2
             return logits.argmax(dim=-1, keepdim=True).repeat_interleave(num_samples, dim=-1)
@@ -789,7 +813,9 @@ class HydragenLlamaForCausalLM(nn.Module):
         self.set_mode(AttentionMode.DECODE)
         graphed = self.graphed_model is not None
         for step in range(max_new_tokens - 1):
-            logits = self(input_ids=feed, position_ids=start + step, use_graph=graphed)[:, -1]
+            # 16-bit logits straight into the sampler unless the caller wants them (fp32, as the reference returns them)
+            logits = self(input_ids=feed, position_ids=start + step, use_graph=graphed,
+                          raw_logits=not return_logits and top_p is None)[:, -1]
             if return_logits:
                 kept_logits.append(logits)
             nxt = self.sample_from_logits(logits, temperature=temperature, top_p=top_p)

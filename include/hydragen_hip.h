@@ -44,7 +44,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
 #define HYD_API __attribute__((visibility("default")))
 
-#define HYD_VERSION 300 /* 0.3.0: two-stream phases + hyd_decode_params.shared_max_workgroups, hyd_decode_two_stream_ok; 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
+#define HYD_VERSION 400 /* 0.4.0: hyd_add_rmsnorm, hyd_swiglu, hyd_sample_tokens (model-shell glue); 0.3.0: two-stream phases + hyd_decode_params.shared_max_workgroups, hyd_decode_two_stream_ok; 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
 #define HYD_MAX_LEVELS 8
 
 enum {
@@ -225,6 +225,64 @@ typedef struct hyd_rope_params {
 } hyd_rope_params;
 
 HYD_API int hyd_rope_append_decode(const hyd_rope_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise glue of the decoder layer around the attention block (the model shell); rows are
+ * tokens, n the hidden / intermediate size, every row 16-byte aligned (n and the row strides multiples of 8).
+ *
+ * hyd_add_rmsnorm: sum_out = residual + x rounded to dtype (the residual stream of llama.py:615-631: `hidden_states =
+ * residual + hidden_states`), norm_out = sum_out * rsqrt(mean(sum_out^2) + eps) * weight with fp32 statistics and one
+ * rounding (transformers' LlamaRMSNorm, constructed at llama.py:605-608,656) in one pass.  residual == NULL: plain
+ * RMSNorm of x (sum_out ignored).  sum_out may alias residual or x.  n <= 16384.
+ *
+ * hyd_swiglu: out = silu(gate) * up (transformers' LlamaMLP, llama.py:2,604: down_proj(act_fn(gate_proj(x)) *
+ * up_proj(x))), fp32 maths, one rounding; gate / up may be the column halves of one fused GEMM output.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hyd_add_rmsnorm_params {
+    const void* x;         /* [rows, n] block output (o_proj / down_proj), row stride x_row_stride        */
+    const void* residual;  /* [rows, n] or NULL                                                          */
+    const void* weight;    /* [n], dtype                                                                 */
+    void* sum_out;         /* [rows, n] or NULL                                                          */
+    void* norm_out;        /* [rows, n]                                                                  */
+    int64_t x_row_stride, residual_row_stride, sum_row_stride, norm_row_stride; /* elements              */
+    int64_t rows;
+    int32_t n;
+    int32_t dtype;         /* HYD_F16 | HYD_BF16                                                         */
+    float eps;
+    int32_t reserved;
+} hyd_add_rmsnorm_params;
+
+HYD_API int hyd_add_rmsnorm(const hyd_add_rmsnorm_params* p, void* stream);
+
+typedef struct hyd_swiglu_params {
+    const void* gate;      /* [rows, n], row stride gate_row_stride                                       */
+    const void* up;        /* [rows, n]                                                                  */
+    void* out;             /* [rows, n]                                                                  */
+    int64_t gate_row_stride, up_row_stride, out_row_stride; /* elements                                  */
+    int64_t rows;
+    int32_t n;
+    int32_t dtype;
+} hyd_swiglu_params;
+
+HYD_API int hyd_swiglu(const hyd_swiglu_params* p, void* stream);
+
+/* Next token of every sequence from its last-position logits: out[row] ~ softmax(logits[row] / temperature), what
+ * `sample_from_logits` (llama.py: softmax(logits / temperature) + torch.multinomial(num_samples=1)) draws, by the
+ * Gumbel-max identity argmax_v(logits_v / temperature + g_v) in one pass over the logits; temperature == 0: plain
+ * argmax (lowest index on ties), as the reference's temperature-0 branch.  The noise is Philox4x32-10 keyed by
+ * (seed, offset, row, column): the same (seed, offset) gives the same tokens on any device / launch geometry; the
+ * caller advances `offset` by one per call.  logits: [rows, n] HYD_F16 | HYD_BF16 | HYD_F32, row stride in elements. */
+typedef struct hyd_sample_params {
+    const void* logits;
+    int64_t* out;          /* [rows]                                                                     */
+    int64_t row_stride;
+    uint64_t seed, offset;
+    int32_t rows, n;
+    int32_t dtype;
+    float temperature;     /* >= 0                                                                       */
+} hyd_sample_params;
+
+HYD_API int hyd_sample_tokens(const hyd_sample_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * All-reduce(sum) of the tensor-parallel block output (hydragen/tp.py:83-87 after down_proj, :108-112 after

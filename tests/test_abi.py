@@ -20,7 +20,7 @@ def test_exports_match_header():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.hyd_version() == 300 == _lib.ABI_VERSION
+    assert lib.hyd_version() == 400 == _lib.ABI_VERSION
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
@@ -39,13 +39,14 @@ def test_dynamic_symbol_table_is_exactly_the_header():
 def test_struct_layout_matches_c():
     """ctypes mirrors must have the C compiler's sizes (checked against a gcc build of the header)."""
     import subprocess, tempfile
-    src = '#include "hydragen_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(hyd_prefix_params), sizeof(hyd_partial), sizeof(hyd_suffix_params), sizeof(hyd_level), sizeof(hyd_decode_params));return 0;}\n'
+    src = '#include "hydragen_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(hyd_prefix_params), sizeof(hyd_partial), sizeof(hyd_suffix_params), sizeof(hyd_level), sizeof(hyd_decode_params), sizeof(hyd_rope_params), sizeof(hyd_add_rmsnorm_params), sizeof(hyd_swiglu_params), sizeof(hyd_sample_params));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         (Path(d) / "s.c").write_text(src)
         subprocess.check_call(["gcc", "-I", str(REPO / "include"), str(Path(d) / "s.c"), "-o", str(Path(d) / "s")])
         sizes = list(map(int, subprocess.check_output([str(Path(d) / "s")]).split()))
     assert sizes == [C.sizeof(PrefixParams), C.sizeof(_lib.Partial), C.sizeof(SuffixParams), C.sizeof(_lib.Level),
-                     C.sizeof(DecodeParams)]
+                     C.sizeof(DecodeParams), C.sizeof(_lib.RopeParams), C.sizeof(_lib.AddRmsnormParams),
+                     C.sizeof(_lib.SwigluParams), C.sizeof(_lib.SampleParams)]
 
 
 def _prefix(**kw):
