@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
         prefix_unit_w64<T, D, CAUSAL, KG, ABL>(a, blockIdx.x, a.vgrid, smem);
     } else {
         for (int vb = blockIdx.x; vb < a.vgrid; vb += gridDim.x) {
-            prefix_unit_w64<T, D, CAUSAL, KG, ABL>(a, vb, a.vgrid, smem);
+            prefix_unit_w64<T, D, CAUSAL, KG, ABL, true>(a, vb, a.vgrid, smem);
             if (vb + (int)gridDim.x < a.vgrid) __syncthreads();  // the unit's LDS merge buffers are the next unit's rings
         }
     }

@@ -43,11 +43,20 @@ __device__ __forceinline__ u32x2 lds_tr16_w(unsigned lds_byte_addr) {
 // Issued from inline asm on purpose: hipcc then neither drains it (vmcnt(0)) in front of the LDS reads of the current
 // blocks nor counts it; the loop waits for it explicitly (dma_wait_w<N>) before its barrier.  M0 is not used by any
 // compiler-generated instruction of this kernel (gfx9 LDS instructions do not read it), so it is not saved.
-__device__ __forceinline__ void dma16w(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :
-                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
-                 : "memory");
+// A wave's NLB pieces of one block sit 1 KiB apart in LDS: M0 is written once per tensor and block (dma_m0) and piece i
+// is addressed through the instruction's immediate offset 1024 i, which the hardware adds to the LDS address AND to the
+// global offset -- the per-lane source offsets of piece i are made 1024 i smaller to compensate (koffb / voffb below).
+__device__ __forceinline__ void dma_m0(unsigned lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory"); }
+// PAD: hipcc does not see inside the asm, so it inserts no wait states between a VALU instruction that writes one of the
+// statement's scalar operands and the buffer_load that reads it (5 wait states on gfx9).  In the one-unit kernel those
+// operands are written by scalar instructions long before; the persistent kernel's unit loop spills scalars to VGPR lanes
+// and restores them (v_readlane) wherever it likes, also right in front of this statement: it pads.
+// tests/test_build_quality.py checks the distance in the compiled code of every instantiation.
+template <int OFF, bool PAD>
+__device__ __forceinline__ void dma16w(u32x4 rsrc, unsigned voff, unsigned soff) {
+    static_assert(OFF >= 0 && OFF < 4096, "12-bit immediate offset");
+    if constexpr (PAD) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ u32x4 make_rsrc_w(const char* base, unsigned bytes) {
     const uint64_t b = (uint64_t)(uintptr_t)base;
@@ -164,7 +173,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // QB: 32-row query blocks per wave.  2 for D <= 128 (64 rows per wave); 1 for D = 256, where one block's O accumulators
 // (8 x 16) and Q fragments (16 x 4) fill the same a[0:191] that two blocks fill at D = 128 (then always KG = 1: 128
 // rows per workgroup, every wave walks all keys, 128 KB of rings).
-template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, int QB = (D > 128 ? 1 : 2)>
+// PERSIST: the unit runs inside a persistent workgroup's unit loop (see dma16w's PAD).
+template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false, int QB = (D > 128 ? 1 : 2)>
 __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
     claim_agprs();
@@ -325,7 +335,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     const int drow = (lane * 16) / RB;        // row inside the instruction
     const int dcp = ((lane * 16) % RB) >> 4;  // 16-byte slot inside the row (LDS side)
     unsigned koffb[NLB], voffb[NLB];  // per-lane source byte offsets relative to the block's first row
-    unsigned kdst[NLB], vdst[NLB];    // wave-uniform LDS byte address of the instruction in ring slot 0
+    unsigned kdst[NLB], vdst[NLB];    // wave-uniform LDS byte address of the instruction in ring slot 0 (piece i = piece 0 + 1024 i)
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_c)smem;
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
@@ -335,8 +345,9 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         const int vs_ = D >= 128 ? (r32 & 3) : ((r32 >> 1) & 1);
         const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
         const int drr = h * 64 + r32;  // row inside the 128-key tile (KG = 2) / the block (KG = 1)
-        koffb[i] = (unsigned)(((int64_t)drr * a.k_ts + kch * 8) * 2);
-        voffb[i] = (unsigned)(((int64_t)drr * a.v_ts + vch * 8) * 2);
+        // piece i is issued with the immediate offset 1024 i (dma16w): drr >= RPI i and a row is >= RB bytes, so >= 0
+        koffb[i] = (unsigned)(((int64_t)drr * a.k_ts + kch * 8) * 2) - 1024u * i;
+        voffb[i] = (unsigned)(((int64_t)drr * a.v_ts + vch * 8) * 2) - 1024u * i;
         const int qh = KG == 2 ? (q * RPI) >> 5 : 0, qr = (q * RPI) & 31;  // wave-uniform
         kdst[i] = __builtin_amdgcn_readfirstlane(lds0 + (qh ? KB_OFF : KA_OFF) + qr * RB);
         vdst[i] = __builtin_amdgcn_readfirstlane(lds0 + V_OFF + (qh * 64 + qr) * RB);
@@ -355,14 +366,14 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         return __builtin_amdgcn_readfirstlane(r0 < nkeys + 128 ? (unsigned)r0 * ts2 : 0x7fff0000u);
     };
     auto dma_block = [&](int b, bool isv) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            if (isv) dma16w(vrs, voffb[i], soff_of(b, v_ts2), vdst[i] + slot_v(b & 3));
-            else dma16w(krs, koffb[i], soff_of(b, k_ts2), kdst[i] + slot_k(b & 3));
-        }
+        dma_m0(isv ? vdst[0] + slot_v(b & 3) : kdst[0] + slot_k(b & 3));
+        static_for<NLB>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value;
+            if (isv) dma16w<1024 * i, PERSIST>(vrs, voffb[i], soff_of(b, v_ts2));
+            else dma16w<1024 * i, PERSIST>(krs, koffb[i], soff_of(b, k_ts2));
+        });
     };
 
-    static_for<QB * NDB>([&](auto I_) { OAcc<decltype(I_)::value>::zero(); });
     // Online-softmax state per query block, in RAW score units (before the scale): the reference maximum m_raw (equal in
     // the two lanes of a row), nms = -sc * m_raw and the threshold thr = m_raw + kTau / sc above which a block's lane
     // maximum forces a new reference.  kMinit is a finite "minus infinity": exp2(sc * (m_old - m_new)) never sees inf - inf.
@@ -467,8 +478,9 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
             else if constexpr (pos == 1) { S[ea + 1] = __builtin_fmaf(S[ea + 1], sc, nms[qb]); asm volatile("" : "+v"(S[ea + 1])); }
             else if constexpr (pos == 3) { S[ea] = fast_exp2(S[ea]); asm volatile("" : "+v"(S[ea])); }
             else if constexpr (pos == 5) { S[ea + 1] = fast_exp2(S[ea + 1]); asm volatile("" : "+v"(S[ea + 1])); }
-            else if constexpr (pos == 2) { su0[qb] += S[ep]; asm volatile("" : "+v"(su0[qb])); }
-            else if constexpr (pos == 4) { su1[qb] += S[ep + 1]; asm volatile("" : "+v"(su1[qb])); }
+            // row sums: the block's first add is S[0] + S[2] (one instruction when pair 1 comes by), not 0 + S[0] and then + S[2]
+            else if constexpr (pos == 2) { if constexpr (ep == 2) su0[qb] = S[0] + S[2]; else if constexpr (ep > 2) su0[qb] += S[ep]; if constexpr (ep >= 2) asm volatile("" : "+v"(su0[qb])); }
+            else if constexpr (pos == 4) { if constexpr (ep == 2) su1[qb] = S[1] + S[3]; else if constexpr (ep > 2) su1[qb] += S[ep + 1]; if constexpr (ep >= 2) asm volatile("" : "+v"(su1[qb])); }
             else {  // element pair kk = ep / 2 -> P^T slot (kk >> 2), word (kk & 3)
                 constexpr int kk = ep / 2;
                 Pw[qb][kk >> 2][kk & 3] = TR::pack2(S[ep], S[ep + 1]);
@@ -556,8 +568,10 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                 constexpr int EVERY = NSLOT / (2 * NLB) > 1 ? 2 : 1;
                 if constexpr ((j % EVERY) == EVERY - 1 && j / EVERY < 2 * NLB) {
                     constexpr int i = j / EVERY;
-                    if constexpr (i < NLB) dma16w(krs, koffb[i], ksoff, kdst[i] + kslot);
-                    else dma16w(vrs, voffb[i - NLB], vsoff, vdst[i - NLB] + vslot);
+                    if constexpr (i == 0) dma_m0(kdst[0] + kslot);
+                    if constexpr (i == NLB) dma_m0(vdst[0] + vslot);
+                    if constexpr (i < NLB) dma16w<1024 * i, PERSIST>(krs, koffb[i], ksoff);
+                    else dma16w<1024 * (i - NLB), PERSIST>(vrs, voffb[i - NLB], vsoff);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -601,6 +615,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         dma_block(2, false);
         dma_block(0, true);
     }
+    static_for<QB * NDB>([&](auto I_) { OAcc<decltype(I_)::value>::zero(); });  // under the first loads' flight
     stampk(1);
     if (NB > 0) dma_wait_w<3 * NLB>();
     else dma_wait_w<0>();

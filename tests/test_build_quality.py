@@ -109,3 +109,57 @@ def test_gqa_suffix_kernel_owns_its_k_registers_while_loads_are_in_flight():
         lo, hi = v["asm"][0][0], v["asm"][-1][0]
         inside = [t for n, t in v["comp"] if lo <= n <= hi]
         assert not inside, f"{name}: compiler-generated AGPR use inside the pipelined loop: {inside[:4]}"
+
+
+def _sregs(tok: str):
+    tok = tok.strip().rstrip(",")
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def valu_sgpr_to_vmem_hazards(asm: str, need: int = 5):
+    """(kernel, buffer instruction, writer) for every buffer_load / buffer_store whose scalar operands (resource, offset)
+    were written by a VALU instruction (v_readlane / v_readfirstlane) fewer than `need` wait states earlier -- the gfx9
+    hazard hipcc pads for its own instructions but cannot see when the memory instruction sits inside an asm statement."""
+    kern, window, bad = None, [], []
+    for ln in asm.splitlines():
+        s = ln.strip()
+        if s.startswith("_Z") and ":" in s:
+            kern, window = s.split(":")[0], []
+            continue
+        if not s or s[0] in ";./":
+            continue
+        op = s.split()[0]
+        if op.startswith(("buffer_load", "buffer_store")):
+            used = set()
+            for tok in s.split(None, 1)[1].replace(",", " ").split():
+                used |= _sregs(tok)
+            ws = 0
+            for pop, pdst in reversed(window):
+                if ws >= need:
+                    break
+                if pdst & used:
+                    bad.append((kern, s, pop))
+                    break
+                m = re.fullmatch(r"s_nop (\d+)", pop)
+                ws += int(m.group(1)) + 1 if m else 1
+        dst = _sregs(s.split(None, 1)[1].split(",")[0]) if op in ("v_readlane_b32", "v_readfirstlane_b32") else set()
+        window = (window + [(s if op == "s_nop" else op, dst)])[-12:]
+    return bad
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+@pytest.mark.parametrize("src", ["prefix_attn_w64.hip", "suffix_attn_gqa.hip", "suffix_attn.hip"])
+def test_asm_memory_instructions_keep_their_distance_from_valu_written_scalars(src):
+    """Found the hard way: the persistent prefix kernel restores spilled scalars with v_readlane right in front of the
+    LDS-DMA asm statements; without wait states the DMA read a stale offset (timing-dependent garbage in the ragged
+    16384-key fixture).  Checked on the compiled code of every instantiation."""
+    assert valu_sgpr_to_vmem_hazards(
+        "_Zk:\nv_readlane_b32 s5, v1, 3\ns_nop 1\nbuffer_load_dwordx4 v1, s[8:11], s5 offen lds\n"), "the checker sees a planted hazard"
+    assert not valu_sgpr_to_vmem_hazards(
+        "_Zk:\nv_readlane_b32 s5, v1, 3\ns_nop 4\nbuffer_load_dwordx4 v1, s[8:11], s5 offen lds\n")
+    bad = valu_sgpr_to_vmem_hazards(_device_asm(src))
+    assert not bad, f"{len(bad)} hazards, first: {bad[:3]}"
