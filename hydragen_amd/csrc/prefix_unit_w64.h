@@ -141,22 +141,32 @@ struct QFrag {  // Q fragment I = qb * NC + c: a[128 + 4 I : 131 + 4 I]
 };
 // every MFMA issued so far has written its result (8-pass XDL: 18 wait states cover any reader)
 __device__ __forceinline__ void acc_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
-// Element phase of one query block's softmax: 56 operations on the 8 element pairs, software-pipelined.  Step st handles
-// {fma, fma, exp2, exp2} of pair st (st < 8) interleaved with {row-sum add, add, pack} of pair st - LAG (st >= LAG).
-// Positions: 0 fma a, 1 fma b, 2 add0 old, 3 exp a, 4 add1 old, 5 exp b, 6 pack old.  Returns step * 8 + position.
-template <int LAG>
-constexpr int elem_op_code(int k) {
-    for (int st = 0; st < 8 + LAG; ++st) {
-        const bool cur = st < 8, old = st >= LAG;
-        const int n = (cur ? 4 : 0) + (old ? 3 : 0);
-        if (k < n) {
-            const int co[4] = {0, 1, 3, 5}, oo[3] = {2, 4, 6};
-            return st * 8 + ((cur && old) ? k : cur ? co[k] : oo[k]);
-        }
-        k -= n;
-    }
-    return -1;
-}
+// Element phase of one query block's softmax: 54 operations on the 8 element pairs p (elements 2p, 2p + 1) -- fa / fb: the
+// fma that applies scale and reference maximum, ea / eb: exp2, sa / sb: the two row-sum chains, pk: pack to 16-bit P^T --
+// as 14 groups, one behind each of the block's MFMAs 2..15.  An MFMA's shadow holds 5 issue slots and exp2 takes two: the
+// 54 operations are 70 slots = 14 x 5, so the table packs every group to exactly five (twelve groups of one exp2 + three
+// plain operations, two of two exp2 + one), with every exp2 at least two instructions (in practice: one MFMA) behind the
+// fma that feeds it -- back to back hipcc pads the pair with an s_nop -- and every add / pack a group behind its exp2s.
+// Code = kind * 8 + pair; kinds: 0 fa, 1 fb, 2 ea, 3 eb, 4 sa, 5 sb, 6 pk.
+#define HYD_OP(kind, pair) ((kind) * 8 + (pair))
+constexpr int kElemOps[54] = {
+    HYD_OP(0, 0), HYD_OP(1, 0), HYD_OP(0, 1), HYD_OP(2, 0),  // g2
+    HYD_OP(3, 0), HYD_OP(1, 1), HYD_OP(0, 2), HYD_OP(1, 2),  // g3
+    HYD_OP(2, 1), HYD_OP(6, 0), HYD_OP(0, 3), HYD_OP(1, 3),  // g4
+    HYD_OP(3, 1), HYD_OP(0, 4), HYD_OP(1, 4), HYD_OP(4, 1),  // g5   (sa of pair 1: S[0] + S[2])
+    HYD_OP(2, 2), HYD_OP(6, 1), HYD_OP(5, 1), HYD_OP(0, 5),  // g6
+    HYD_OP(3, 2), HYD_OP(1, 5), HYD_OP(4, 2), HYD_OP(0, 6),  // g7
+    HYD_OP(2, 3), HYD_OP(6, 2), HYD_OP(5, 2), HYD_OP(1, 6),  // g8
+    HYD_OP(3, 3), HYD_OP(4, 3), HYD_OP(0, 7), HYD_OP(1, 7),  // g9
+    HYD_OP(2, 4), HYD_OP(6, 3), HYD_OP(3, 4),                // g10
+    HYD_OP(2, 5), HYD_OP(5, 3), HYD_OP(4, 4), HYD_OP(5, 4),  // g11
+    HYD_OP(3, 5), HYD_OP(6, 4), HYD_OP(2, 6),                // g12
+    HYD_OP(3, 6), HYD_OP(4, 5), HYD_OP(5, 5), HYD_OP(6, 5),  // g13
+    HYD_OP(2, 7), HYD_OP(4, 6), HYD_OP(5, 6), HYD_OP(6, 6),  // g14
+    HYD_OP(3, 7), HYD_OP(4, 7), HYD_OP(5, 7), HYD_OP(6, 7),  // g15
+};
+#undef HYD_OP
+constexpr int kElemGroupStart[15] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 39, 42, 46, 50, 54};
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -463,28 +473,24 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         //   g0-g1 lane-local maximum of the 16 raw scores (max3 tree) and ONE compare against the threshold.  Only when
         //         some lane exceeds it (cold, wave-uniform) are the half-wave exchange, the new reference, alpha and the
         //         O / l rescale executed -- the hot path never touches m, nms or alpha.
-        //   g2-g15: 56 element operations, software-pipelined over the 8 element pairs: step s = {fma, fma, exp2, exp2} of
-        //         pair s interleaved with {row-sum add, add, pack} of pair s - LAG (scalar f32 ops on purpose: packed f32
-        //         VALU beside MFMAs costs more than the two scalar instructions it replaces).
-        constexpr int LAG = 2;
+        //   g2-g15: 54 element operations in the order of kElemOps, five issue slots per group (scalar f32 ops on purpose: packed
+        //         f32 VALU beside MFMAs costs more than the two scalar instructions it replaces).
         auto elem_op = [&](auto K_, int qb) __attribute__((always_inline)) {
             f32x16& S = Sr[qb];
-            constexpr int code = elem_op_code<LAG>(decltype(K_)::value);
-            constexpr int step = code >> 3, pos = code & 7;
-            constexpr int ea = 2 * step, ep = 2 * (step - LAG);  // elements of this step's pair / of the old pair
-            if constexpr ((ABL & 64) || ((ABL & 32) && (pos == 3 || pos == 5)) || ((ABL & 128) && (pos == 2 || pos == 4 || pos == 6)))
+            constexpr int code = kElemOps[decltype(K_)::value];
+            constexpr int kind = code >> 3, pr = code & 7, e0 = 2 * pr, e1 = 2 * pr + 1;
+            if constexpr ((ABL & 64) || ((ABL & 32) && (kind == 2 || kind == 3)) || ((ABL & 128) && kind >= 4))
                 return;
-            else if constexpr (pos == 0) { S[ea] = __builtin_fmaf(S[ea], sc, nms[qb]); asm volatile("" : "+v"(S[ea])); }
-            else if constexpr (pos == 1) { S[ea + 1] = __builtin_fmaf(S[ea + 1], sc, nms[qb]); asm volatile("" : "+v"(S[ea + 1])); }
-            else if constexpr (pos == 3) { S[ea] = fast_exp2(S[ea]); asm volatile("" : "+v"(S[ea])); }
-            else if constexpr (pos == 5) { S[ea + 1] = fast_exp2(S[ea + 1]); asm volatile("" : "+v"(S[ea + 1])); }
+            else if constexpr (kind == 0) { S[e0] = __builtin_fmaf(S[e0], sc, nms[qb]); asm volatile("" : "+v"(S[e0])); }
+            else if constexpr (kind == 1) { S[e1] = __builtin_fmaf(S[e1], sc, nms[qb]); asm volatile("" : "+v"(S[e1])); }
+            else if constexpr (kind == 2) { S[e0] = fast_exp2(S[e0]); asm volatile("" : "+v"(S[e0])); }
+            else if constexpr (kind == 3) { S[e1] = fast_exp2(S[e1]); asm volatile("" : "+v"(S[e1])); }
             // row sums: the block's first add is S[0] + S[2] (one instruction when pair 1 comes by), not 0 + S[0] and then + S[2]
-            else if constexpr (pos == 2) { if constexpr (ep == 2) su0[qb] = S[0] + S[2]; else if constexpr (ep > 2) su0[qb] += S[ep]; if constexpr (ep >= 2) asm volatile("" : "+v"(su0[qb])); }
-            else if constexpr (pos == 4) { if constexpr (ep == 2) su1[qb] = S[1] + S[3]; else if constexpr (ep > 2) su1[qb] += S[ep + 1]; if constexpr (ep >= 2) asm volatile("" : "+v"(su1[qb])); }
-            else {  // element pair kk = ep / 2 -> P^T slot (kk >> 2), word (kk & 3)
-                constexpr int kk = ep / 2;
-                Pw[qb][kk >> 2][kk & 3] = TR::pack2(S[ep], S[ep + 1]);
-                asm volatile("" ::"v"(Pw[qb][kk >> 2][kk & 3]));
+            else if constexpr (kind == 4) { if constexpr (pr == 1) su0[qb] = S[0] + S[2]; else su0[qb] += S[e0]; asm volatile("" : "+v"(su0[qb])); }
+            else if constexpr (kind == 5) { if constexpr (pr == 1) su1[qb] = S[1] + S[3]; else su1[qb] += S[e1]; asm volatile("" : "+v"(su1[qb])); }
+            else {  // element pair pr -> P^T slot (pr >> 2), word (pr & 3)
+                Pw[qb][pr >> 2][pr & 3] = TR::pack2(S[e0], S[e1]);
+                asm volatile("" ::"v"(Pw[qb][pr >> 2][pr & 3]));
             }
         };
         auto valu_group = [&](auto G_, int qb) __attribute__((always_inline)) {
@@ -505,7 +511,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                     upf[qb] = tmax[qb] > thr[qb];
                     asm volatile("" ::"v"(tmax[qb]));
                 } else {
-                    constexpr int k0 = ((g - 2) * 56) / 14, k1 = ((g - 1) * 56) / 14;
+                    constexpr int k0 = kElemGroupStart[g - 2], k1 = kElemGroupStart[g - 1];
                     static_for<k1 - k0>([&](auto K_) __attribute__((always_inline)) {
                         elem_op(std::integral_constant<int, k0 + decltype(K_)::value>{}, qb);
                     });
@@ -594,7 +600,12 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                 for (int qb = 0; qb < QB; ++qb) l_run[qb] *= alpha[qb];
             }
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) l_run[qb] += su0[qb] + su1[qb];
+            for (int qb = 0; qb < QB; ++qb) {  // pinned scalar adds: left alone, hipcc packs the two blocks' sums into v_pk_add_f32 (+ an s_nop)
+                float t = su0[qb] + su1[qb];
+                asm volatile("" : "+v"(t));
+                l_run[qb] += t;
+                asm volatile("" : "+v"(l_run[qb]));
+            }
         }
     };
 
