@@ -144,8 +144,8 @@ __device__ __forceinline__ void acc_drain() { asm volatile("s_nop 15\n\ts_nop 7"
 // Element phase of one query block's softmax: 54 operations on the 8 element pairs p (elements 2p, 2p + 1) -- fa / fb: the
 // fma that applies scale and reference maximum, ea / eb: exp2, sa / sb: the two row-sum chains, pk: pack to 16-bit P^T --
 // as 14 groups, one behind each of the block's MFMAs 2..15.  An MFMA's shadow holds 5 issue slots and exp2 takes two: the
-// 54 operations are 70 slots = 14 x 5, so the table packs every group to exactly five (twelve groups of one exp2 + three
-// plain operations, two of two exp2 + one), with every exp2 at least two instructions (in practice: one MFMA) behind the
+// 54 operations are 70 slots = 14 x 5, so the table packs every group to exactly five (one exp2 + three plain operations,
+// two exp2 + one, or five plain ones), with every exp2 at least two instructions (in practice: one MFMA) behind the
 // fma that feeds it -- back to back hipcc pads the pair with an s_nop -- and every add / pack a group behind its exp2s.
 // Code = kind * 8 + pair; kinds: 0 fa, 1 fb, 2 ea, 3 eb, 4 sa, 5 sb, 6 pk.
 #define HYD_OP(kind, pair) ((kind) * 8 + (pair))
@@ -162,11 +162,11 @@ constexpr int kElemOps[54] = {
     HYD_OP(2, 5), HYD_OP(5, 3), HYD_OP(4, 4), HYD_OP(5, 4),  // g11
     HYD_OP(3, 5), HYD_OP(6, 4), HYD_OP(2, 6),                // g12
     HYD_OP(3, 6), HYD_OP(4, 5), HYD_OP(5, 5), HYD_OP(6, 5),  // g13
-    HYD_OP(2, 7), HYD_OP(4, 6), HYD_OP(5, 6), HYD_OP(6, 6),  // g14
-    HYD_OP(3, 7), HYD_OP(4, 7), HYD_OP(5, 7), HYD_OP(6, 7),  // g15
+    HYD_OP(2, 7), HYD_OP(4, 6), HYD_OP(3, 7),                // g14
+    HYD_OP(5, 6), HYD_OP(6, 6), HYD_OP(4, 7), HYD_OP(5, 7), HYD_OP(6, 7),  // g15  (no exp2 left: nothing here reads a result of its own group)
 };
 #undef HYD_OP
-constexpr int kElemGroupStart[15] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 39, 42, 46, 50, 54};
+constexpr int kElemGroupStart[15] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 39, 42, 46, 49, 54};
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -444,13 +444,13 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         auto ldv = [&](int p, int h) -> u32x2 { return ldv_at(p, h, VOFF); };
         // softmax state of this iteration
         float t0[QB], t1[QB], t2[QB], t3[QB], t4[QB], tmax[QB], alpha[QB], su0[QB], su1[QB];
-        bool upf[QB];
+        uint64_t upb[QB];
         bool pend = false;  // a new reference maximum was adopted in this iteration: O and l are rescaled at its end
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             t0[qb] = t1[qb] = t2[qb] = t3[qb] = t4[qb] = tmax[qb] = su0[qb] = su1[qb] = 0.f;
-            alpha[qb] = 1.f;
-            upf[qb] = false;
+            // alpha is only written by the cold branch that sets `pend` and only read under `pend`: no per-iteration 1.0
+            upb[qb] = 0ull;
         }
         if constexpr (SM && MASK) {
             bool need_mask = !bvalid || (kw + 32 > kend);
@@ -508,7 +508,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                     t0[qb] = fmaxf(fmaxf(t0[qb], t1[qb]), S[15]);
                     t2[qb] = fmaxf(fmaxf(t2[qb], t3[qb]), t4[qb]);
                     tmax[qb] = fmaxf(t0[qb], t2[qb]);
-                    upf[qb] = tmax[qb] > thr[qb];
+                    upb[qb] = __builtin_amdgcn_ballot_w64(tmax[qb] > thr[qb]);  // lanes above the threshold (a scalar pair: no VALU select)
                     asm volatile("" ::"v"(tmax[qb]));
                 } else {
                     constexpr int k0 = kElemGroupStart[g - 2], k1 = kElemGroupStart[g - 1];
@@ -546,7 +546,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
             });
             if constexpr (SM && !(ABL & 4) && (j * NG) / NSLOT <= 1 && 1 < ((j + 1) * NG) / NSLOT) {
                 // both query blocks know their lane maxima: adopt a new reference maximum?  (cold, wave-uniform)
-                if (__builtin_amdgcn_ballot_w64(upf[0] || upf[QB - 1]) != 0ull) {
+                if ((upb[0] | upb[QB - 1]) != 0ull) {
                     asm volatile("" ::: "memory");  // keep this a branch
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
