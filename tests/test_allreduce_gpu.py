@@ -125,3 +125,61 @@ def test_missing_peer_times_out_with_status():
     assert status != 0
     assert dt < 60
     assert torch.equal(x, x0)
+
+
+def _rccl_worker(port, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)  # "nccl" IS RCCL on ROCm
+        x = torch.randn(1024, 4096, device="cuda", dtype=torch.bfloat16)
+        want = x.clone()
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert torch.equal(x, want)
+        # the reference's in-graph collective (llama.py:849-854): the all-reduce of a [B, 1, hidden] block output captured
+        # behind a kernel of ours and replayed
+        from hydragen_amd import layer_ops
+        w = torch.ones(4096, device="cuda", dtype=torch.bfloat16)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                y = layer_ops.add_rms_norm(want, None, w, 1e-5)[1]
+                dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = layer_ops.add_rms_norm(want, None, w, 1e-5)[1]
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        ref = layer_ops.add_rms_norm(want, None, w, 1e-5)[1].clone()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+        ret["ok"] = True
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        ret["err"] = repr(e)
+
+
+def test_rccl_initialises_reduces_and_captures_with_one_rank():
+    """One GPU allows one RCCL rank (RCCL refuses two ranks on a device): at least the library loads, builds a communicator,
+    runs its all-reduce kernel and lets it be captured into a HIP graph next to our kernels -- the multi-rank run needs a
+    multi-GPU node (tp.py:83-87,108-112; llama.py:849-854)."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(port, ret))
+    p.start()
+    p.join(180)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL single-rank worker hung")
+    assert ret.get("ok"), ret.get("err")
