@@ -337,3 +337,31 @@ def test_readme_cache_workflows(graph):
     assert model.get_num_used_shared_caches() == 1
     model.empty_shared_cache()
     assert model.get_num_used_shared_caches() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_layer_glue_equals_the_spelled_out_layers(dtype):
+    """HydragenLlamaModel.forward with every residual add fused into the following RMSNorm (hyd_add_rmsnorm) and the SwiGLU
+    kernel, against the same weights run layer by layer as llama.py:610-633 spells it (torch add, torch rms_norm, torch
+    silu * up): same dataflow, so the hidden states agree to a few roundings of the 16-bit residual stream."""
+    from hydragen_amd import layer_ops
+
+    model = make_model(dtype, layers=3)
+    m = model.model
+    ids = torch.randint(1, model.config.vocab_size, (5, 9), device=DEV)
+    pos = torch.arange(9, device=DEV)[None].expand(5, 9).contiguous()
+    model.setup_caches(max_unique_batch_size=5, max_unique_seq_length=32, max_shared_batch_sizes=[], max_shared_seq_lengths=[])
+    model.set_mode("unique-prefill")
+    with torch.no_grad():
+        fused = m(ids, pos)
+        supported = layer_ops.supported
+        layer_ops.supported = lambda *a, **k: False  # the torch form everywhere
+        try:
+            model.setup_caches(max_unique_batch_size=5, max_unique_seq_length=32, max_shared_batch_sizes=[], max_shared_seq_lengths=[])
+            plain = m(ids, pos)
+        finally:
+            layer_ops.supported = supported
+    assert fused.dtype == dtype and fused.shape == plain.shape
+    err = (fused.float() - plain.float()).abs().max().item()
+    scale = plain.float().abs().max().item()
+    assert err <= (2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9) * scale, (err, scale)
