@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-paper-sweep", action="store_true", help="skip the reference microbenchmark's own sweep corners (8 q / 1 kv heads)")
     ap.add_argument("--two-stream", action="store_true",
                     help="steps replay the two-stream form of the operator instead of the one-call form (A/B; DESIGN 4.8)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not count HBM bytes with rocprofv3 --pmc child passes of this command (then: the committed passes, if they match)")
     ap.add_argument("--trials", type=int, default=3, help="repetitions of the K-step schedule after the headline region (spread)")
     ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -447,14 +449,74 @@ def main():
         dist.destroy_process_group()
 
 
+def _live_traffic(args):
+    """HBM bytes per launch of the two kernels, COUNTED NOW: two `rocprofv3 --pmc` child passes (FETCH_SIZE, WRITE_SIZE;
+    counters only, no trace domain) of this very command line with the untimed legs off, read from the rocpd database.
+    FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes, MI355X_MICROARCH.md, HBM section); both are KB.
+    None when rocprofv3 is missing, when this process is itself being profiled, or when a pass fails."""
+    import shutil, sqlite3, subprocess, tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if exe is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    child = [sys.executable, str(REPO / "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
+             "--prefix", str(args.prefix), "--max-suffix", str(args.max_suffix), "--qheads", str(args.qheads), "--kvheads", str(args.kvheads),
+             "--dim", str(args.dim), "--trials", "0", "--no-cpu-baseline", "--no-protocol", "--no-model", "--no-accuracy",
+             "--no-paper-sweep", "--no-nosharing", "--no-live-traffic"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "run", "--"] + child, cwd="/tmp", env=env, timeout=240,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+                dbs = list(Path(d).rglob("*.db"))
+                if not dbs:
+                    return None
+                cur = sqlite3.connect(str(dbs[0])).cursor()
+                for name, n, avg in cur.execute("select kernel_name, count(*), avg(value) from counters_collection "
+                                                "where counter_name = ? group by kernel_name", (counter,)):
+                    key = "suffix" if "suffix_attn" in name else "prefix" if "prefix_attn" in name else None
+                    if key:
+                        means[(key, counter)] = (float(avg), int(n))
+    except Exception:  # a profiler that cannot run here must never cost the bench line
+        return None
+    launches = launch_schedule(args.steps, args.warmup, 0, args.max_suffix)
+    e = 2
+    out = {"launches": len(launches),
+           "suffix_algorithmic": sum(2 * e * args.kvheads * args.dim * args.batch * s_ + 2 * args.batch * args.qheads * args.dim * e
+                                     + 4 * args.batch * args.qheads for s_ in launches) / len(launches),
+           "prefix_algorithmic": 2 * args.prefix * args.kvheads * args.dim * e + 2 * args.batch * args.qheads * args.dim * e + 4 * args.batch * args.qheads}
+    for key in ("suffix", "prefix"):
+        f, w = means.get((key, "FETCH_SIZE")), means.get((key, "WRITE_SIZE"))
+        if f is None or w is None or f[1] != len(launches) or w[1] != len(launches):
+            return None  # not the launch schedule this accounting assumes
+        out[key] = (2.0 * f[0] + w[0]) * 1024.0
+    return out
+
+
 def _attach_traffic(suffix_roof, prefix_roof, args, world):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes, only when they were collected with THIS
-    command line (same shape and the same suffix schedule); otherwise only the measured traffic / algorithmic ratio."""
+    """roofline.traffic = HBM bytes per launch.  First choice: counted in this run by rocprofv3 --pmc child passes of the
+    same command line (_live_traffic).  Otherwise the committed passes (profiles/traffic_latest.json), and then only when
+    they were collected with THIS command line (same shape, same suffix schedule); else just their traffic / algorithmic
+    ratio."""
+    if world != 1:  # the counters describe the single-GPU shape
+        return
+    live = None if args.no_live_traffic else _live_traffic(args)
+    if live is not None:
+        for roof, key in ((suffix_roof, "suffix"), (prefix_roof, "prefix")):
+            roof["traffic"] = live[key]
+            roof["traffic_over_algorithmic"] = live[key] / live[f"{key}_algorithmic"]
+            roof["traffic_source"] = (f"counted in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child passes, counters "
+                                      f"only) of this command line with the untimed legs off; mean over the {live['launches']} launches of a pass "
+                                      "(capture warm-ups, warm-up steps, timed steps: bench.launch_schedule); FETCH_SIZE doubled per the "
+                                      "gfx950 note in MI355X_MICROARCH.md")
+        return
     tr = REPO / "profiles" / "traffic_latest.json"
-    if not tr.exists() or world != 1:  # the counters were collected on the single-GPU shape
+    if not tr.exists():
         return
     t = json.loads(tr.read_text())
-    same = (world == 1 and t.get("steps") == args.steps and t.get("batch") == args.batch and t.get("prefix") == args.prefix
+    same = (t.get("steps") == args.steps and t.get("batch") == args.batch and t.get("prefix") == args.prefix
             and t.get("max_suffix") == args.max_suffix and t.get("qheads") == args.qheads and t.get("kvheads") == args.kvheads)
     for roof, key in ((suffix_roof, "suffix"), (prefix_roof, "prefix")):
         b = t.get(f"{key}_hbm_bytes_per_launch")

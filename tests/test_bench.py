@@ -67,6 +67,11 @@ def test_bench_single_gpu_line_is_complete():
     assert abs(res["trials"]["trial0_us_per_step"] - res["ms_per_step"] * 1e3) < 1e-6
     assert set(res["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(res["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "c1_full"}
+    # HBM bytes per launch are counted in the run itself (rocprofv3 --pmc child passes), for both kernels
+    for key in ("roofline", "roofline_other"):
+        roof = res[key]
+        assert roof["traffic"] and roof["traffic_source"].startswith("counted in this run"), roof.get("traffic_source")
+        assert 0.95 < roof["traffic_over_algorithmic"] < 1.25, roof
 
 
 def test_launch_schedule_is_what_a_profiler_sees():

@@ -13,7 +13,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --trials 0 --no-cpu-baseline --no-protocol --no-model --no-accuracy --no-paper-sweep"
+CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --trials 0 --no-cpu-baseline --no-protocol --no-model --no-accuracy --no-paper-sweep --no-live-traffic"
 cd /tmp
 rm -rf /tmp/prof_*
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o run -- $CMD > $OUT/${TAG}_bench_profiled.json 2>/tmp/prof_stats.log
