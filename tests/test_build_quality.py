@@ -163,3 +163,26 @@ def test_asm_memory_instructions_keep_their_distance_from_valu_written_scalars(s
         "_Zk:\nv_readlane_b32 s5, v1, 3\ns_nop 4\nbuffer_load_dwordx4 v1, s[8:11], s5 offen lds\n")
     bad = valu_sgpr_to_vmem_hazards(_device_asm(src))
     assert not bad, f"{len(bad)} hazards, first: {bad[:3]}"
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_prefix_kernels_leave_m0_to_the_dma_statements():
+    """The prefix pass writes M0 once per tensor and block and addresses the block's pieces through immediate offsets
+    (prefix_unit_w64.h, dma_m0 / dma16w): between that write and the block's last LDS-DMA no compiler-generated instruction
+    may touch M0.  Checked the strong way: outside the asm statements nothing in these kernels names m0 at all."""
+    inasm, kern, bad, writes = False, None, [], 0
+    for ln in _device_asm("prefix_attn_w64.hip").splitlines():
+        t = ln.strip()
+        if t.startswith("_Z") and ":" in t:
+            kern = t.split(":")[0]
+        elif t.startswith(";;#ASMSTART"):
+            inasm = True
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
+        elif re.search(r"\bm0\b", t.split(";")[0]):
+            if inasm:
+                writes += t.startswith("s_mov_b32 m0")
+            else:
+                bad.append((kern, t))
+    assert writes > 100, "the DMA statements' M0 writes were not found: did the asm markers change?"
+    assert not bad, bad[:3]
