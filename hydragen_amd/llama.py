@@ -315,7 +315,9 @@ class HydragenLlamaAttention(nn.Module):
         self.use_fused_decode = True
         self._qkv: Optional[Tensor] = None
 
-    def forward(self, hidden_states: Tensor, position_ids: Tensor):
+    def forward(self, hidden_states: Tensor, position_ids: Tensor, shared_len: Optional[Tensor] = None):
+        """shared_len: the per-sequence total shared length [B] (get_shared_len) when the caller already has it -- it is
+        the same for every layer of a forward pass, and computing it is three small launches (~17 us) per layer."""
         bsz, q_len, _ = hidden_states.shape
         self._qkv = w = _fused_weight(self._qkv, (self.q_proj, self.k_proj, self.v_proj))
         if w is not None:
@@ -335,7 +337,10 @@ class HydragenLlamaAttention(nn.Module):
             # seq_lens = that index + 1  (replaces llama.py:485-501,565-569 and the scatter_ of :236-262)
             from .fused_decode import rope_append_decode
 
-            shared_len = None if self.disable_hydragen else self.kv_cache.get_shared_len(bsz)
+            if self.disable_hydragen:
+                shared_len = None
+            elif shared_len is None:
+                shared_len = self.kv_cache.get_shared_len(bsz)
             q, seq_lens = rope_append_decode(q, k, v, cos, sin, position_ids, shared_len,
                                              self.kv_cache.per_completion_k_cache, self.kv_cache.per_completion_v_cache)
             key_states = self.kv_cache.per_completion_k_cache[:bsz]
@@ -457,9 +462,16 @@ class HydragenLlamaModel(nn.Module):
         # once and writes the new stream and its normalised form, instead of an add and a norm launch per block.
         first = layers[0].input_layernorm
         _, normed = layer_ops.add_rms_norm(h, None, first.weight, first.variance_epsilon)
+        # decode: the shared lengths (llama.py:317-330) once per forward instead of once per layer -- the layers' caches are
+        # filled in lockstep, so every layer would compute the same [B] tensor with three small launches
+        a0 = layers[0].self_attn
+        shared_len = None
+        if a0.mode == AttentionMode.DECODE and a0.kv_cache is not None and not a0.disable_hydragen and h.shape[1] == 1:
+            shared_len = a0.kv_cache.get_shared_len(h.shape[0])
         for i, layer in enumerate(layers):
             post = layer.post_attention_layernorm
-            h, normed = layer_ops.add_rms_norm(layer.self_attn(normed, position_ids), h, post.weight, post.variance_epsilon)
+            h, normed = layer_ops.add_rms_norm(layer.self_attn(normed, position_ids, shared_len=shared_len), h, post.weight,
+                                               post.variance_epsilon)
             nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else self.norm
             h, normed = layer_ops.add_rms_norm(layer.mlp(normed), h, nxt.weight, nxt.variance_epsilon)
         return normed
