@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-SOURCES = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "layer_ops.hip", "allreduce.hip"]
+SOURCES = ["api.hip", "prefix_attn_w64.hip", "prefix_attn_w64_f16.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "layer_ops.hip", "allreduce.hip"]
 HEADERS = sorted(h.name for h in HERE.glob("*.h")) + ["../../include/hydragen_hip.h"]
 LIB = HERE / "libhydragen_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -43,7 +43,7 @@ def _compile(src: str, force: bool) -> Path:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]

@@ -135,6 +135,7 @@ struct SampleArgs {  // layer_ops.hip: out[row] ~ softmax(logits[row] / T) (Gumb
 
 // launchers (defined next to the kernels); return hipError_t as int
 int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int grid, hipStream_t s);
+int launch_prefix_w64_f16(const PrefixArgs& a, int D, bool causal, int grid, hipStream_t s);  // prefix_attn_w64_f16.hip
 int launch_rope_append(const RopeArgs& a, int dtype, int D, hipStream_t s);
 int launch_add_rmsnorm(const NormArgs& a, int dtype, hipStream_t s);
 int launch_swiglu(const SwigluArgs& a, int dtype, hipStream_t s);

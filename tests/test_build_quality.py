@@ -14,6 +14,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # file -> (max VGPRs per kernel matching the regex)
 LIMITS = {
     "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512)],   # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs)
+    "prefix_attn_w64_f16.hip": [(r"prefix_attn_w64_kernel", 512)],  # the fp16 instantiations of the same template
     # 2 waves / SIMD (two 8-KiB V tiles per wave bound the occupancy anyway); the count includes the 64 AGPRs of the K sets
     "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256)],
     "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1ELi\dE", 80)],  # <T, D, R = 1, WPU = 1, NPRE>, MHA decode: 6 waves / SIMD
@@ -64,7 +65,7 @@ def test_prefix_kernel_owns_its_accumulator_registers():
     """prefix_attn_w64.hip keeps the O accumulators and the Q fragments in literal AGPRs (a[0:191]) that only its own
     inline-asm statements name.  That is safe only while hipcc itself never touches an AGPR in those kernels (it would,
     for spills): no instruction outside ;;#ASMSTART / ;;#ASMEND may name one, and every kernel must allocate >= 160."""
-    out = _device_asm("prefix_attn_w64.hip")
+    out = _device_asm("prefix_attn_w64.hip") + _device_asm("prefix_attn_w64_f16.hip")  # bf16 / fp16 instantiations
     inasm, bad = False, []
     for line in out.splitlines():
         t = line.strip()
@@ -78,7 +79,7 @@ def test_prefix_kernel_owns_its_accumulator_registers():
     counts = [int(x) for x in re.findall(r"\.agpr_count:\s+(\d+)", out)]
     assert counts and min(counts) >= 160, counts
     # (register numbers are assembler expressions of template constants; hipcc prints the larger ones in hex)
-    assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and re.search(r"a\[(128|0x80):(131|0x83)\]", out)
+    assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and "v_mfma_f32_32x32x16_f16 a[0:15]" in out and re.search(r"a\[(128|0x80):(131|0x83)\]", out)
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
@@ -152,7 +153,7 @@ def valu_sgpr_to_vmem_hazards(asm: str, need: int = 5):
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["prefix_attn_w64.hip", "suffix_attn_gqa.hip", "suffix_attn.hip"])
+@pytest.mark.parametrize("src", ["prefix_attn_w64.hip", "prefix_attn_w64_f16.hip", "suffix_attn_gqa.hip", "suffix_attn.hip"])
 def test_asm_memory_instructions_keep_their_distance_from_valu_written_scalars(src):
     """Found the hard way: the persistent prefix kernel restores spilled scalars with v_readlane right in front of the
     LDS-DMA asm statements; without wait states the DMA read a stale offset (timing-dependent garbage in the ragged
@@ -171,7 +172,7 @@ def test_prefix_kernels_leave_m0_to_the_dma_statements():
     (prefix_unit_w64.h, dma_m0 / dma16w): between that write and the block's last LDS-DMA no compiler-generated instruction
     may touch M0.  Checked the strong way: outside the asm statements nothing in these kernels names m0 at all."""
     inasm, kern, bad, writes = False, None, [], 0
-    for ln in _device_asm("prefix_attn_w64.hip").splitlines():
+    for ln in (_device_asm("prefix_attn_w64.hip") + _device_asm("prefix_attn_w64_f16.hip")).splitlines():
         t = ln.strip()
         if t.startswith("_Z") and ":" in t:
             kern = t.split(":")[0]

@@ -9,7 +9,7 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 src, out = REPO / "hydragen_amd" / "csrc", REPO / "build_probe"
 out.mkdir(exist_ok=True)
-srcs = ["api.hip", "prefix_attn_w64.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "allreduce.hip"]
+srcs = ["api.hip", "prefix_attn_w64.hip", "prefix_attn_w64_f16.hip", "suffix_attn.hip", "suffix_attn_gqa.hip", "combine.hip", "rope_append.hip", "layer_ops.hip", "allreduce.hip"]
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DHYD_ABLATION_BUILD", "-Wno-unused-function"]
 
 
