@@ -380,6 +380,7 @@ int run_level_small(const hyd_prefix_params& pp, const PrefixPlan& pl, void* out
     a.rows = pl.qpg * pl.g;
     a.units = pp.sb * pp.Hkv;
     a.scale_log2e = scale_log2e_of(pp.softmax_scale, pp.D);
+    a.shared_kv = 1;
     const int rc = launch_suffix_gqa(a, pp.dtype, pp.D, s);
     return rc ? fail(HYD_ERR_LAUNCH, "small-level kernel launch failed: hip error %d", rc) : HYD_OK;
 }

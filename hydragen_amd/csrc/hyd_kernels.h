@@ -68,6 +68,7 @@ struct SuffixArgs {
     float scale_log2e;
     int32_t packed;  // shapes allow the lane-group path for short sequences (set by launch_suffix)
     int32_t n_pre;   // leading 16-bit partials the kernels fetch under the K/V stream (0..2, set by run_suffix)
+    int32_t shared_kv;  // the keys are read by several workgroups (a small shared level on the grouped-query kernel): no non-temporal hint
     PartialDev partials[kMaxCombine];
 };
 

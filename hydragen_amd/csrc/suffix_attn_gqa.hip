@@ -36,7 +36,8 @@ namespace hyd {
 // barriers).  4: the unit's 32-key steps are dealt round-robin to the 4 waves of a 256-thread workgroup and their
 // (m, l, O) merged through LDS at the end -- for shapes with too few units to fill the chip with one wave each (C3: 1024
 // units on 256 CUs, C5: 2048), where nothing but more waves hides the per-step load latency.
-template <typename T, int D, int WPU>
+// NT: K/V loads carry the non-temporal hint (suffix_gqa_common.h): the unique phase, where every key is read once.
+template <typename T, int D, int WPU, bool NT>
 __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int RB = D * 2;        // bytes per K/V row
@@ -132,11 +133,11 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
         const unsigned ks0 = (unsigned)key0 * k_ts2, ks1 = ks0 + 16u * k_ts2, vsoff = (unsigned)key0 * v_ts2;
         static_for_g<NCH>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
-            KReg<BUF * 8 + c>::template load<64 * c>(krs, kvoff, ks0);
-            KReg<BUF * 8 + 4 + c>::template load<64 * c>(krs, kvoff, ks1);
+            KReg<BUF * 8 + c>::template load<64 * c, NT>(krs, kvoff, ks0);
+            KReg<BUF * 8 + 4 + c>::template load<64 * c, NT>(krs, kvoff, ks1);
         });
 #pragma unroll
-        for (int i = 0; i < NVD; ++i) dma16_g(vrs, vvoff[i], vsoff, vt0 + BUF * TILE + i * 1024);
+        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs, vvoff[i], vsoff, vt0 + BUF * TILE + i * 1024);
     };
     auto step = [&](auto BUF_, int key0) __attribute__((always_inline)) {
         constexpr int BUF = decltype(BUF_)::value;
@@ -336,13 +337,18 @@ static int launch_gqa_t(const SuffixArgs& a, hipStream_t s) {
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_LDS_PAD")) {
         pad = (size_t)atoi(e);
-        static const hipError_t rc_ = hipFuncSetAttribute(reinterpret_cast<const void*>(suffix_attn_gqa_kernel<T, D, 1>),
+        static const hipError_t rc_ = hipFuncSetAttribute(reinterpret_cast<const void*>(suffix_attn_gqa_kernel<T, D, 1, true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         (void)rc_;
     }
 #endif
-    if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1>), grid, dim3(64), pad, s, a);
+    if (a.shared_kv) {  // a small shared level: its keys are read by several workgroups, default cache policy
+        if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1, false>), grid, dim3(64), pad, s, a);
+    } else {
+        if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1, true>), grid, dim3(64), pad, s, a);
+    }
     return (int)hipGetLastError();
 }
 

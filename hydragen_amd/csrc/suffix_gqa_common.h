@@ -36,12 +36,23 @@ __device__ __forceinline__ u32x4 make_rsrc_g(const void* base, unsigned bytes) {
     return r;
 }
 // 64 lanes x 16 B, global -> LDS [lds_dst, +1 KiB) (lane-linear image), zero fill past the resource's end
+// NT: non-temporal hint for K/V that is read once (a sequence's own cache: the unique phase).  Measured at C5 (277 MB per
+// launch): 101.5 -> 96.5 us cold and 140 -> 97 us under the reference's write-flush protocol (the stream no longer competes
+// with the flush's dirty lines for the memory-side cache); keys that several workgroups share (a small shared level run on
+// this kernel) keep the default policy (C4 cold: 146 us against 149 with the hint).
+template <bool NT>
 __device__ __forceinline__ void dma16_g(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+                     : "memory");
 }
 // K fragment I of the two register sets (set = I / 8, 16-key half = (I / 4) & 1, 32-dim chunk = I & 3) in a[4I : 4I+3]
 template <int I>
@@ -49,11 +60,16 @@ struct KReg;
 #define HYD_KREG(I, A, B, C, E)                                                                                          \
     template <>                                                                                                          \
     struct KReg<I> {                                                                                                     \
-        template <int OFF> /* 16 B per lane, bounds-checked: rows past the resource's end read as zero */                \
+        template <int OFF, bool NT> /* 16 B per lane, bounds-checked: rows past the resource's end read as zero */      \
         static __device__ __forceinline__ void load(u32x4 rsrc, unsigned voff, unsigned soff) {                          \
-            asm volatile("buffer_load_dwordx4 a[" #A ":" #E "], %0, %1, %2 offen offset:%3" ::"v"(voff), "s"(rsrc),      \
-                         "s"(soff), "i"(OFF)                                                                             \
-                         : "memory", "a" #A, "a" #B, "a" #C, "a" #E);                                                    \
+            if constexpr (NT)                                                                                            \
+                asm volatile("buffer_load_dwordx4 a[" #A ":" #E "], %0, %1, %2 offen offset:%3 nt" ::"v"(voff),          \
+                             "s"(rsrc), "s"(soff), "i"(OFF)                                                              \
+                             : "memory", "a" #A, "a" #B, "a" #C, "a" #E);                                                \
+            else                                                                                                         \
+                asm volatile("buffer_load_dwordx4 a[" #A ":" #E "], %0, %1, %2 offen offset:%3" ::"v"(voff), "s"(rsrc),  \
+                             "s"(soff), "i"(OFF)                                                                         \
+                             : "memory", "a" #A, "a" #B, "a" #C, "a" #E);                                                \
         }                                                                                                                \
         template <typename T, bool FIRST> /* s (+)= K_frag . q^T */                                                      \
         static __device__ __forceinline__ void qk(f32x4& s, const u32x4& q) {                                            \
