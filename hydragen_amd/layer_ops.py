@@ -17,9 +17,10 @@ from .flash import _dtype_code, _require_gpu, _stream
 
 
 def supported(x: Tensor, n_max: int = 16384) -> bool:
-    """Shapes the kernels take: 16-bit CUDA rows, contiguous in the last dimension, a multiple of 8 wide."""
+    """Shapes the kernels take: 16-bit CUDA rows, contiguous in the last dimension, a multiple of 8 wide, every row
+    16-byte aligned (what the C entry points check); anything else takes the torch form in the model shell."""
     return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= n_max
-            and x.stride(-1) == 1)
+            and x.stride(-1) == 1 and x.data_ptr() % 16 == 0 and all(st % 8 == 0 for st in x.stride()[:-1]))
 
 
 def _rows(t: Tensor) -> Tensor:
