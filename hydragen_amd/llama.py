@@ -330,8 +330,7 @@ class HydragenLlamaAttention(nn.Module):
         v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
         cos, sin = self.rotary_emb.cos_cached, self.rotary_emb.sin_cached
 
-        fused = (self.mode == AttentionMode.DECODE and self.use_fused_decode and q_len == 1
-                 and not self.disable_attention)
+        fused = self.mode == AttentionMode.DECODE and self.use_fused_decode and q_len == 1
         if fused:
             # one HIP kernel: RoPE(q, k) at absolute positions, append k/v at (position - shared length),
             # seq_lens = that index + 1  (replaces llama.py:485-501,565-569 and the scatter_ of :236-262)
@@ -345,7 +344,11 @@ class HydragenLlamaAttention(nn.Module):
                                              self.kv_cache.per_completion_k_cache, self.kv_cache.per_completion_v_cache)
             key_states = self.kv_cache.per_completion_k_cache[:bsz]
             value_states = self.kv_cache.per_completion_v_cache[:bsz]
-            if not self.kv_cache.has_shared() or self.disable_hydragen:
+            if self.disable_attention:
+                # llama.py:433-437,503-504: attention replaced by the identity on the rotated q.  The same preamble kernel as
+                # the other modes, so that this mode's step is the decode step minus exactly the attention kernels.
+                attn_output = q
+            elif not self.kv_cache.has_shared() or self.disable_hydragen:
                 attn_output, _ = flash_attention_seqlen(q, key_states, value_states, seq_len=seq_lens)
             else:
                 attn_output = hydragen_attention_on_caches(q, key_states, value_states,
