@@ -69,6 +69,7 @@ class DecodeParams(C.Structure):
         ("n_levels", C.c_int32), ("phase", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("shared_max_workgroups", C.c_int32), ("f32_partials", C.c_int32),
+        ("single_launch_small", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -259,8 +259,10 @@ def _launch_decode(lib, p, two_stream: bool, stream: int):
     """Issue the operator described by `p`: one call, or the three calls of the two-stream form."""
     if not two_stream:
         p.phase, p.shared_max_workgroups = HYD_PHASE_ALL, 0
+        p.single_launch_small = 1  # problems that are launch latency, not work, run as one kernel (hydragen_hip.h)
         _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
         return
+    p.single_launch_small = 0
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     p.shared_max_workgroups = TWO_STREAM_PREFIX_CUS

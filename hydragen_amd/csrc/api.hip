@@ -580,6 +580,24 @@ int hyd_sample_tokens(const hyd_sample_params* p, void* stream) {
     return rc ? fail(HYD_ERR_LAUNCH, "sample kernel launch failed: hip error %d", rc) : HYD_OK;
 }
 
+// hyd_decode_params.single_launch_small: one uniform shared level that already counts as small (few query rows per
+// (group, kv head), short prefix), unique keys present, the same token strides in the shared and the unique tensors, and
+// so few keys in all that the call is launch latency.  Measured per graph-replayed call (tests/probes/single_launch_probe.py,
+// units x keys = B * Hkv * (P + S)): 1152 keys (BASELINE config 1) 6.8 -> 4.1 us, 2176 keys 11.4 -> 8.1, 8072 keys (two
+// sequences on a 1000-key prefix) 19.5 -> 16.5, 8704 keys (32 sequences) 14.0 -> 14.1: even.  Shapes only: capture-safe.
+constexpr int64_t kSingleLaunchMaxKeys = 8192;
+static bool decode_runs_as_one_launch(const hyd_decode_params* p, const hyd_prefix_params* pps, const PrefixPlan* pls, const bool* small) {
+    const hyd_suffix_params& sp = p->suffix;
+    if (p->phase != HYD_PHASE_ALL || !p->single_launch_small || p->n_levels != 1 || !small[0] || sp.kv_len <= 0) return false;
+    const hyd_prefix_params& pp = pps[0];
+    if (pp.cu_seqlens_k || pp.sb <= 0 || sp.B % pp.sb != 0) return false;  // (a small level runs unsplit whatever the plan says)
+    if (pp.k_tok_stride != sp.k_tok_stride || pp.v_tok_stride != sp.v_tok_stride) return false;
+    if ((int64_t)sp.B * sp.Hkv * ((int64_t)pp.kv_len + sp.kv_len) > kSingleLaunchMaxKeys) return false;
+    SuffixArgs a;
+    fill_suffix_args(&sp, &a);
+    return suffix_gqa_eligible(a, sp.D, /*any_shape=*/true);
+}
+
 // attention.py:273-274: a single shared level and no unique keys -> the prefix result IS the answer
 static bool decode_is_prefix_only(const hyd_decode_params* p) { return p->n_levels == 1 && p->suffix.kv_len == 0; }
 
@@ -741,6 +759,18 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         n_parts += (pls[i].nsplit == 1 || small[i]) ? 1 : pls[i].nsplit;
     }
     if (n_parts + (two_stream ? 1 : 0) > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "%d partials (more than %d)", n_parts, kMaxCombine);
+    if (decode_runs_as_one_launch(p, pps, pls, small)) {
+        // launch latency, not work: the grouped-query kernel walks the group's shared keys, then the sequence's own
+        SuffixArgs a;
+        fill_suffix_args(&sp, &a);
+        a.pk = pps[0].k; a.pv = pps[0].v;
+        a.pk_gs = pps[0].k_group_stride; a.pk_hs = pps[0].k_head_stride;
+        a.pv_gs = pps[0].v_group_stride; a.pv_hs = pps[0].v_head_stride;
+        a.p_len = pps[0].kv_len;
+        a.p_per = sp.B / pps[0].sb;
+        rc = launch_suffix_gqa(a, sp.dtype, sp.D, s);
+        return rc ? fail(HYD_ERR_LAUNCH, "single-launch decode kernel failed: hip error %d", rc) : HYD_OK;
+    }
     const size_t levels_bytes = need;
     if (two_stream) need += unique_partial_bytes(sp);
     if (need > 0 && (!p->workspace || p->workspace_bytes < need))

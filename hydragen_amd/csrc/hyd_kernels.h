@@ -69,6 +69,12 @@ struct SuffixArgs {
     int32_t packed;  // shapes allow the lane-group path for short sequences (set by launch_suffix)
     int32_t n_pre;   // leading 16-bit partials the kernels fetch under the K/V stream (0..2, set by run_suffix)
     int32_t shared_kv;  // the keys are read by several workgroups (a small shared level on the grouped-query kernel): no non-temporal hint
+    // grouped-query kernel only: a shared-prefix segment walked before the unit's own keys (tiny problems: the whole
+    // operator in one launch).  Sequence b reads rows [0, p_len) of group b / p_per; token strides equal k_ts / v_ts.
+    const void* pk;
+    const void* pv;
+    int64_t pk_gs, pk_hs, pv_gs, pv_hs;
+    int32_t p_len, p_per;
     PartialDev partials[kMaxCombine];
 };
 

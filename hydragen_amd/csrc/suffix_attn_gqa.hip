@@ -80,6 +80,16 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
     const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
     const u32x4 krs = make_rsrc_g(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs, (unsigned)len * k_ts2);
     const u32x4 vrs = make_rsrc_g(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs, (unsigned)len * v_ts2);
+    // Tiny problems (SuffixArgs::pk): the group's shared prefix is walked first, through its own resources, then the
+    // unit's own keys -- the (m, l, O) state simply carries over, and the whole operator is this one launch.
+    const bool has_pre = a.pk != nullptr;
+    const int gi = has_pre ? b / a.p_per : 0;
+    const u32x4 krs_p = make_rsrc_g(static_cast<const uint16_t*>(has_pre ? a.pk : a.k) + (int64_t)gi * a.pk_gs + (int64_t)hk * a.pk_hs,
+                                    has_pre ? (unsigned)a.p_len * k_ts2 : 0u);
+    const u32x4 vrs_p = make_rsrc_g(static_cast<const uint16_t*>(has_pre ? a.pv : a.v) + (int64_t)gi * a.pv_gs + (int64_t)hk * a.pv_hs,
+                                    has_pre ? (unsigned)a.p_len * v_ts2 : 0u);
+    u32x4 krs_c = krs, vrs_c = vrs;  // the segment being walked
+    int seg_len = len;
     // K fragment (A operand): key = l15 of a 16-key block, dims 32 c + 8 g4 .. + 8
     const unsigned kvoff = (unsigned)l15 * k_ts2 + 16u * g4;
     // V DMA: instruction i covers tile rows [i * RPI, +RPI); the XOR swizzle of the LDS image is applied to the source chunk
@@ -133,11 +143,11 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
         const unsigned ks0 = (unsigned)key0 * k_ts2, ks1 = ks0 + 16u * k_ts2, vsoff = (unsigned)key0 * v_ts2;
         static_for_g<NCH>([&](auto C_) {
             constexpr int c = decltype(C_)::value;
-            KReg<BUF * 8 + c>::template load<64 * c, NT>(krs, kvoff, ks0);
-            KReg<BUF * 8 + 4 + c>::template load<64 * c, NT>(krs, kvoff, ks1);
+            KReg<BUF * 8 + c>::template load<64 * c, NT>(krs_c, kvoff, ks0);
+            KReg<BUF * 8 + 4 + c>::template load<64 * c, NT>(krs_c, kvoff, ks1);
         });
 #pragma unroll
-        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs, vvoff[i], vsoff, vt0 + BUF * TILE + i * 1024);
+        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs_c, vvoff[i], vsoff, vt0 + BUF * TILE + i * 1024);
     };
     auto step = [&](auto BUF_, int key0) __attribute__((always_inline)) {
         constexpr int BUF = decltype(BUF_)::value;
@@ -154,8 +164,8 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int kb = key0 + 4 * g4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            p[i] = (kb + i < len) ? s0[i] * sc : -INFINITY;
-            p[4 + i] = (kb + 16 + i < len) ? s1[i] * sc : -INFINITY;
+            p[i] = (kb + i < seg_len) ? s0[i] * sc : -INFINITY;
+            p[4 + i] = (kb + 16 + i < seg_len) ? s1[i] * sc : -INFINITY;
         }
         float tmax = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
         tmax = quad_max(tmax);
@@ -183,11 +193,13 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
         // are read by plain VALU code next (the rescale of the next step, the epilogue): drain the matrix pipeline
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     };
-    {
+    for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline (its last wait is vmcnt(0))
         using std::integral_constant;
+        if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_len = a.p_len; }
+        else { krs_c = krs; vrs_c = vrs; seg_len = len; }
         constexpr int stride = 32 * WPU;
         const int k_first = wave * 32;
-        const int nst = len > k_first ? (len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
+        const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
         auto key_of = [&](int j) { return k_first + j * stride; };
         if (nst > 0) {
             issue(integral_constant<int, 0>{}, key_of(0));
@@ -328,7 +340,7 @@ static int launch_gqa_t(const SuffixArgs& a, hipStream_t s) {
     const int chunks = (a.rows + 15) / 16;
     // shapes only: fewer than 4 one-wave units per CU (measured: B=32, 8/1 heads, 1152 keys 48 -> 31 us; at 1024 and
     // 2048 units -- C3, C5 -- one wave per unit is as fast or faster), and enough keys to deal out
-    bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len >= 128;
+    bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len + (a.pk ? a.p_len : 0) >= 128;
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
 #endif

@@ -184,6 +184,13 @@ typedef struct hyd_decode_params {
     int32_t f32_partials;          /* 0: an unsplit level's partial is stored in the 16-bit dtype (what the reference
                                     * does: its flash-attn output is 16-bit, README.md:488-490); 1: kept fp32 (one
                                     * rounding less, + 2 bytes per output element written and read back)           */
+    int32_t single_launch_small;   /* 1 (HYD_PHASE_ALL only): a problem so small that it is launch latency, not work --
+                                    * one uniform shared level with few query rows per (group, kv head), short prefix,
+                                    * few keys in all -- runs as ONE kernel that walks the group's shared keys and then
+                                    * the sequence's own (what the no-sharing baseline does, without the replicated
+                                    * prefix).  The result then differs from the phase-split forms by their roundings of
+                                    * the partial.  0: always the prefix pass + suffix pass pair.                    */
+    int32_t reserved;
 } hyd_decode_params;
 
 HYD_API size_t hyd_decode_workspace_bytes(const hyd_decode_params* p);

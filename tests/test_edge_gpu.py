@@ -6,8 +6,8 @@ import pytest
 import torch
 
 from oracle import hydragen_oracle as O
-from tests.cases import _round
-from tests.gpu_util import assert_close, dev
+from tests.cases import _round, make_case
+from tests.gpu_util import assert_close, assert_close_l2, case_to_device, dev
 
 pytestmark = pytest.mark.gpu
 
@@ -246,3 +246,47 @@ def test_cached_parameter_blocks_follow_the_callers_tensors():
     torch.cuda.synchronize()
     want2 = O.hydragen_attention_nopad(f(q[:4]), f(k[:4]), f(v[:4]), [f(sk)], [f(sv)], lens[:4].cpu().numpy())
     assert_close(f(out2), want2, dt, "other shapes")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("sizes,qh,kvh,dim", [
+    ([[64], [8, 8, 8, 8]], 4, 4, 64),                 # BASELINE config 1 literal
+    ([[3], [6, 7]], 8, 1, 128),                       # ragged unique lengths, 8 query heads on one kv head
+    ([[130, 130], [1, 200, 31, 2, 17, 150]], 8, 2, 128),  # two groups, 4 waves per unit (>= 128 keys allocated, few units)
+    ([[33], [1]], 8, 8, 64),                          # one sequence
+    ([[1000], [5, 9]], 16, 4, 128),                   # the longest prefix that still counts as a small level
+])
+def test_single_launch_form_of_tiny_problems(sizes, qh, kvh, dim, dtype):
+    """hyd_decode_params.single_launch_small: problems that are launch latency run as ONE kernel (the grouped-query kernel
+    walks the group's shared keys, then the sequence's own).  Against the float64 oracle with the operator's usual bounds,
+    and against the two-pass form of the same call (which rounds a partial in between)."""
+    import ctypes as C
+    from hydragen_amd import attention as A, _lib
+    from oracle import hydragen_oracle as O
+
+    case = make_case(sizes=sizes, qheads=qh, kvheads=kvh, dim=dim, dtype=dtype, seed=4242, force_seq_lens=True)
+    d = case_to_device(case)
+    want = O.hydragen_attention(case["q"], case["k"], case["v"], case["shared_ks"], case["shared_vs"], case["shared_cu_seq_lens"],
+                                case["shared_max_seq_lens"], case["use_varlens"], case["seq_lens"])
+    seen = []
+    orig = A._launch_decode
+
+    def spy(lib, p, two_stream, stream, single=1):
+        p.phase, p.shared_max_workgroups, p.single_launch_small = _lib.HYD_PHASE_ALL, 0, single
+        _lib.check(lib.hyd_decode_attn_fused(C.byref(p), stream))
+        seen.append(single)
+
+    outs = {}
+    try:
+        for single in (1, 0):
+            A._PARAM_CACHE.clear()
+            A._launch_decode = lambda lib, p, ts, st, single=single: spy(lib, p, ts, st, single)
+            outs[single] = A.hydragen_attention(**d).float().cpu().numpy()
+    finally:
+        A._launch_decode = orig
+        A._PARAM_CACHE.clear()
+    assert seen == [1, 0]
+    assert_close_l2(outs[1], want, dtype, "single launch vs float64 oracle")
+    assert_close_l2(outs[0], want, dtype, "two passes vs float64 oracle")
+    if dtype == "bf16":  # the two-pass form rounds a bf16 partial in between: equal bits would mean the flag was ignored
+        assert not np.array_equal(outs[0], outs[1])
