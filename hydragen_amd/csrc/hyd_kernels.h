@@ -39,6 +39,7 @@ struct PrefixArgs {
     int32_t row_blocks, nsplit, split_len;
     int32_t vgrid;    // units = sb * Hkv * nsplit * row_blocks; the launch grid may be smaller (persistent workgroups)
     int32_t wg_rows;  // query rows per workgroup: 128, or 256 (pipelined kernel, D = 128, large row counts)
+    int32_t waves;    // waves per workgroup: 4 (one per SIMD, 64-row waves) or 8 (two per SIMD, 32-row waves; D = 128)
     int32_t lse_layout, out_f32;
     float scale_log2e;
     FastDiv div_row_blocks, div_nsplit, div_hkv, div_g;  // the unit / row decode divides by these four

@@ -15,30 +15,48 @@ template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = fa
 __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (!PERSIST) {
-        prefix_unit_w64<T, D, CAUSAL, KG, ABL>(a, blockIdx.x, a.vgrid, smem);
+        prefix_unit_w64<T, D, CAUSAL, KG, ABL, false, 4>(a, blockIdx.x, a.vgrid, smem);
     } else {
         for (int vb = blockIdx.x; vb < a.vgrid; vb += gridDim.x) {
-            prefix_unit_w64<T, D, CAUSAL, KG, ABL, true>(a, vb, a.vgrid, smem);
+            prefix_unit_w64<T, D, CAUSAL, KG, ABL, true, 4>(a, vb, a.vgrid, smem);
             if (vb + (int)gridDim.x < a.vgrid) __syncthreads();  // the unit's LDS merge buffers are the next unit's rings
         }
     }
 }
 
-template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false>
+// The 8-wave kernel (two waves per SIMD, one workgroup per unit) is held to 160 architectural VGPRs -- amdgpu_num_vgpr(80)
+// counts VGPRs and accumulator registers alike and the kernel uses no accumulator register -- so that v[160:255] stay the
+// unit's own (prefix_unit_w64.h, RegsV).
+template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(80))) void prefix_attn_w64x8_kernel(const PrefixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    prefix_unit_w64<T, D, CAUSAL, KG, ABL, false, 8>(a, blockIdx.x, a.vgrid, smem);
+}
+
+template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false, int NW = 4>
 inline int launch_prefix_w64_k(const PrefixArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (KG == 2 ? 2 : 1) * 256 * (D * 2) + 4 * 2 * 128 * sizeof(float);
-    auto kern = prefix_attn_w64_kernel<T, D, CAUSAL, KG, ABL, PERSIST>;
+    auto kern = [] {
+        if constexpr (NW == 8) return prefix_attn_w64x8_kernel<T, D, CAUSAL, KG, ABL>;
+        else return prefix_attn_w64_kernel<T, D, CAUSAL, KG, ABL, PERSIST>;
+    }();
+    static_assert(NW == 4 || !PERSIST, "the 8-wave kernel runs one unit per workgroup");
     // once per instantiation, thread-safe (C++11 static initialisation); the value never changes afterwards
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_rc != hipSuccess) return (int)attr_rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a);
     return (int)hipGetLastError();
 }
 
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
 inline int launch_prefix_w64_t(const PrefixArgs& a, int grid, hipStream_t s) {
-    if (grid >= a.vgrid) return launch_prefix_w64_k<T, D, CAUSAL, KG, ABL, false>(a, a.vgrid, s);
+    if (grid >= a.vgrid) {
+        if constexpr (D == 128) {
+            if (a.waves == 8) return launch_prefix_w64_k<T, D, CAUSAL, KG, ABL, false, 8>(a, a.vgrid, s);
+        }
+        return launch_prefix_w64_k<T, D, CAUSAL, KG, ABL, false>(a, a.vgrid, s);
+    }
     // fewer workgroups than units: only the decode entry asks for it, and its levels are never causal
     if constexpr (!CAUSAL && ABL == 0) return launch_prefix_w64_k<T, D, CAUSAL, KG, ABL, true>(a, grid, s);
     else return (int)hipErrorInvalidValue;

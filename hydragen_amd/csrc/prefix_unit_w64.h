@@ -31,6 +31,15 @@ namespace {
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_w;
 
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 __device__ __forceinline__ u32x2 lds_tr16_w(unsigned lds_byte_addr) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_w)(uintptr_t)lds_byte_addr);
     return __builtin_bit_cast(u32x2, t);
@@ -85,10 +94,16 @@ __device__ __forceinline__ void dma_wait_w() { asm volatile("s_waitcnt vmcnt(%0)
 // definition serves the 8 O blocks and the 16 Q fragments.  These statements carry no clobber lists; claim_agprs()
 // below names a[0:191] once per unit, which is what sizes the kernel descriptor's accumulator file.
 #define HYD_A10(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
+template <int N>
 __device__ __forceinline__ void claim_agprs() {
-    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
-                 HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), HYD_A10(9), HYD_A10(10), HYD_A10(11), HYD_A10(12), HYD_A10(13),
-                 HYD_A10(14), HYD_A10(15), HYD_A10(16), HYD_A10(17), HYD_A10(18), "a190", "a191");
+    static_assert(N == 96 || N == 192, "accumulator registers of a unit");
+    if constexpr (N == 192)
+        asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
+                     HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), HYD_A10(9), HYD_A10(10), HYD_A10(11), HYD_A10(12), HYD_A10(13),
+                     HYD_A10(14), HYD_A10(15), HYD_A10(16), HYD_A10(17), HYD_A10(18), "a190", "a191");
+    else
+        asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
+                     HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), "a90", "a91", "a92", "a93", "a94", "a95");
 }
 #undef HYD_A10
 #define HYD_IRP16 ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\t"
@@ -122,11 +137,10 @@ struct OAcc {  // O block I = qb * NDB + db: a[16 I : 16 I + 15]
                      : "n"(R0));
     }
 };
-#undef HYD_IRP16
 
-template <int I>
-struct QFrag {  // Q fragment I = qb * NC + c: a[128 + 4 I : 131 + 4 I]
-    static constexpr int R0 = 128 + 4 * I;
+template <int I, int QBASE>
+struct QFrag {  // Q fragment I = qb * NC + c: a[QBASE + 4 I : QBASE + 3 + 4 I]
+    static constexpr int R0 = QBASE + 4 * I;
     template <int OFF>
     static __device__ __forceinline__ void load(const void* p) {
         asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(p), "n"(R0), "n"(R0 + 3), "n"(OFF) : "memory");
@@ -141,6 +155,105 @@ struct QFrag {  // Q fragment I = qb * NC + c: a[128 + 4 I : 131 + 4 I]
 };
 // every MFMA issued so far has written its result (8-pass XDL: 18 wait states cover any reader)
 __device__ __forceinline__ void acc_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+
+// Where the O accumulators and the Q fragments live: literal accumulator registers, O block I in a[16 I : 16 I + 15], Q
+// fragment I in a[QBASE + 4 I : QBASE + 4 I + 3]; NCLAIM registers are claimed for the kernel descriptor.
+//   one wave per SIMD (4-wave workgroups, 64-row waves or D = 256):  QBASE = 128, NCLAIM = 192 of the wave's 512 registers
+//   two waves per SIMD (8-wave workgroups, 32-row waves, D <= 128):  QBASE = 64,  NCLAIM = 96; hipcc then splits the 256
+//   registers of a wave 128 / 128 and fits its own values into 128 architectural VGPRs (no spills, no accumulator
+//   register of its own: tests/test_build_quality.py).
+template <int QBASE, int NCLAIM>
+struct RegsA {
+    __device__ __forceinline__ void claim() { claim_agprs<NCLAIM>(); }
+    template <int I, bool BF>
+    __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) { OAcc<I>::template pv<BF>(a, b); }
+    template <int I>
+    __device__ __forceinline__ void zero() { OAcc<I>::zero(); }
+    // cold path of the softmax: every O block of query block qb times alpha[qb] (pend is wave-uniform)
+    template <int NQB, int NDB_>
+    __device__ __forceinline__ void rescale(bool pend, const float (&alpha)[NQB]) {
+        if (pend) {
+            acc_drain();
+            static_for<NQB * NDB_>([&](auto I_) { constexpr int I = decltype(I_)::value; OAcc<I>::scale(alpha[I / NDB_]); });
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void read(float (&x)[16]) { OAcc<I>::read(x); }
+    template <int I, int OFF>
+    __device__ __forceinline__ void qload(const void* p) { QFrag<I, QBASE>::template load<OFF>(p); }
+    template <int I, bool BF, bool FIRST>
+    __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) { QFrag<I, QBASE>::template qk<BF, FIRST>(s, a); }
+    __device__ __forceinline__ void drain() { acc_drain(); }
+};
+// RegsV -- two waves per SIMD (8-wave workgroups, 32-row waves, 256 registers per wave): no accumulator registers at all
+// (on gfx950 every MFMA operand may be an architectural VGPR).  O block I lives in the literal registers
+// v[160 + 16 I : 175 + 16 I], Q fragment I in v[224 + 4 I : 227 + 4 I], named in the asm text only, exactly as RegsA names
+// its accumulator registers.  What keeps hipcc out of them is the kernel's register budget: the 8-wave kernel is declared
+// amdgpu_num_vgpr(80), which for a function that uses no accumulator register means "at most 160 architectural VGPRs"
+// (v0..v159 are all it can allocate; a function that does use accumulator registers is held to a 128 / 128 split, too few
+// for this loop, and hipcc then parks values in whatever accumulator registers it believes free).  claim() names v255
+// once so that the kernel descriptor allocates the whole file; tests/test_build_quality.py asserts that no
+// compiler-generated instruction names a register above v159 and that nothing spills.
+template <int I>
+struct OAccV {  // O block I: v[160 + 16 I : 175 + 16 I]
+    static constexpr int R0 = 160 + 16 * I;
+    template <bool BF>
+    static __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) {
+        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 v[%2:%3], %0, %1, v[%2:%3]" ::"v"(a), "v"(b), "n"(R0), "n"(R0 + 15));
+        else asm volatile("v_mfma_f32_32x32x16_f16 v[%2:%3], %0, %1, v[%2:%3]" ::"v"(a), "v"(b), "n"(R0), "n"(R0 + 15));
+    }
+    static __device__ __forceinline__ void zero() { asm volatile(HYD_IRP16 "v_mov_b32 v[%0+\\r], 0\n\t.endr\n\ts_nop 1" ::"n"(R0)); }
+    static __device__ __forceinline__ void scale(float f) {
+        asm volatile(HYD_IRP16 "v_mul_f32 v[%1+\\r], v[%1+\\r], %0\n\t.endr\n\ts_nop 1" ::"v"(f), "n"(R0));
+    }
+    static __device__ __forceinline__ void read(float (&x)[16]) {
+        asm volatile("v_mov_b32 %0, v[%16]\n\tv_mov_b32 %1, v[%16+1]\n\tv_mov_b32 %2, v[%16+2]\n\tv_mov_b32 %3, v[%16+3]\n\t"
+                     "v_mov_b32 %4, v[%16+4]\n\tv_mov_b32 %5, v[%16+5]\n\tv_mov_b32 %6, v[%16+6]\n\tv_mov_b32 %7, v[%16+7]\n\t"
+                     "v_mov_b32 %8, v[%16+8]\n\tv_mov_b32 %9, v[%16+9]\n\tv_mov_b32 %10, v[%16+10]\n\tv_mov_b32 %11, v[%16+11]\n\t"
+                     "v_mov_b32 %12, v[%16+12]\n\tv_mov_b32 %13, v[%16+13]\n\tv_mov_b32 %14, v[%16+14]\n\tv_mov_b32 %15, v[%16+15]"
+                     : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]), "=v"(x[4]), "=v"(x[5]), "=v"(x[6]), "=v"(x[7]), "=v"(x[8]),
+                       "=v"(x[9]), "=v"(x[10]), "=v"(x[11]), "=v"(x[12]), "=v"(x[13]), "=v"(x[14]), "=v"(x[15])
+                     : "n"(R0));
+    }
+};
+template <int I>
+struct QFragV {  // Q fragment I: v[224 + 4 I : 227 + 4 I]
+    static constexpr int R0 = 224 + 4 * I;
+    template <int OFF>
+    static __device__ __forceinline__ void load(const void* p) {
+        asm volatile("global_load_dwordx4 v[%1:%2], %0, off offset:%3" ::"v"(p), "n"(R0), "n"(R0 + 3), "n"(OFF) : "memory");
+    }
+    template <bool BF, bool FIRST>
+    static __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) {
+        if constexpr (BF && FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, v[%2:%3], 0" : "=&v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+        else if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, v[%2:%3], %0" : "+v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+        else if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, v[%2:%3], 0" : "=&v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, v[%2:%3], %0" : "+v"(s) : "v"(a), "n"(R0), "n"(R0 + 3));
+    }
+};
+struct RegsV {
+    __device__ __forceinline__ void claim() { asm volatile("" ::: "v255"); }
+    template <int I, bool BF>
+    __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) { OAccV<I>::template pv<BF>(a, b); }
+    template <int I>
+    __device__ __forceinline__ void zero() { OAccV<I>::zero(); }
+    template <int NQB, int NDB_>
+    __device__ __forceinline__ void rescale(bool pend, const float (&alpha)[NQB]) {
+        if (pend) {
+            acc_drain();
+            static_for<NQB * NDB_>([&](auto I_) { constexpr int I = decltype(I_)::value; OAccV<I>::scale(alpha[I / NDB_]); });
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void read(float (&x)[16]) { OAccV<I>::read(x); }
+    template <int I, int OFF>
+    __device__ __forceinline__ void qload(const void* p) { QFragV<I>::template load<OFF>(p); }
+    template <int I, bool BF, bool FIRST>
+    __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) { QFragV<I>::template qk<BF, FIRST>(s, a); }
+    __device__ __forceinline__ void drain() { acc_drain(); }
+};
+
+#undef HYD_IRP16
 // Element phase of one query block's softmax: 54 operations on the 8 element pairs p (elements 2p, 2p + 1) -- fa / fb: the
 // fma that applies scale and reference maximum, ea / eb: exp2, sa / sb: the two row-sum chains, pk: pack to 16-bit P^T --
 // as 14 groups, one behind each of the block's MFMAs 2..15.  An MFMA's shadow holds 5 issue slots and exp2 takes two: the
@@ -167,27 +280,26 @@ constexpr int kElemOps[54] = {
 };
 #undef HYD_OP
 constexpr int kElemGroupStart[15] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 39, 42, 46, 49, 54};
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
 
 }  // namespace
 
-// ABL: development-only timing ablations (bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
+// ABL: development-only timing ablations (bit13 / bit14: see the DMA issue; bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
 // bit4 no barrier in the loop, bit5 no exp2, bit6 no element phase, bit7 no row sums / pack); only ABL = 0 ships.
 // QB: 32-row query blocks per wave.  2 for D <= 128 (64 rows per wave); 1 for D = 256, where one block's O accumulators
 // (8 x 16) and Q fragments (16 x 4) fill the same a[0:191] that two blocks fill at D = 128 (then always KG = 1: 128
 // rows per workgroup, every wave walks all keys, 128 KB of rings).
 // PERSIST: the unit runs inside a persistent workgroup's unit loop (see dma16w's PAD).
-template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false, int QB = (D > 128 ? 1 : 2)>
+// NW: waves per workgroup.  4 = one wave per SIMD, 64-row waves (512 registers per wave); 8 = two waves per SIMD, 32-row
+// waves (256 registers per wave: 96 accumulator registers for O / Q + 128 of hipcc's): the same rows per workgroup, the
+// same rings, the same pipeline per wave -- half the MFMAs per wave and iteration, and the SIMD issues one wave's VALU /
+// LDS / DMA instructions in the shadow of the other wave's MFMAs (tests/probes/pingpong_probe.hip: 36.5 against 46.7 - 53
+// cycles per MFMA and SIMD for the instruction mix of this loop).
+template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false, int NW = 4, int QB = ((D > 128 || NW == 8) ? 1 : 2)>
 __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
-    claim_agprs();
+    static_assert(NW == 4 || (NW == 8 && QB == 1 && D <= 128), "two waves per SIMD: 32-row waves, D <= 128");
+    std::conditional_t<NW == 8, RegsV, RegsA<128, 192>> regs;
+    regs.claim();
     if constexpr ((ABL & 4096) != 0) asm volatile("s_nop 0");  // development: shifts the whole stream by 4 bytes (code-placement probe)
     static_assert(QB == 1 || QB == 2, "query blocks per wave");
     static_assert(D <= 128 || (QB == 1 && KG == 1), "D = 256 runs one query block per wave and unsplit key tiles");
@@ -195,13 +307,14 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     constexpr int RB = D * 2;            // bytes per K/V row
     constexpr int NC = D / 16;           // k-chunks of the QK^T contraction
     constexpr int NDB = D / 32;          // 32-wide d blocks of O^T
-    constexpr int RWG = (KG == 2 ? 2 : 4) * WROWS;            // query rows per workgroup
+    constexpr int NRW = NW / KG;                              // row sub-blocks (waves per key half)
+    constexpr int RWG = NRW * WROWS;                          // query rows per workgroup
     constexpr int BROWS = KG == 2 ? 64 : 32;                  // K (or V) rows staged per iteration
-    constexpr int NLB = BROWS * RB / 1024 / 4;                // DMA instructions per wave per tensor per iteration
+    constexpr int NLB = BROWS * RB / 1024 / NW;               // DMA instructions per wave per tensor per iteration
     constexpr int RPI = 1024 / RB;                            // rows per DMA instruction
     static_assert(NLB >= 1, "every wave issues at least one DMA instruction per tensor and iteration");
     constexpr int RING_BYTES = (KG == 2 ? 512 : 256) * RB;
-    float* mlbuf = reinterpret_cast<float*>(smem + RING_BYTES);  // [4 waves][QB][2][64] (KG = 2 merge)
+    float* mlbuf = reinterpret_cast<float*>(smem + RING_BYTES);  // [NW waves][QB][2][64] (KG = 2 merge)
 
     unsigned tst[6] = {0, 0, 0, 0, 0, 0};  // ABL bit 11: cycle stamps of workgroup 0 (development builds only)
     auto stampk = [&](int k) __attribute__((always_inline)) {
@@ -219,8 +332,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = KG == 2 ? wave >> 1 : 0;   // key half of every 128-key tile this wave computes on
-    const int rw = KG == 2 ? wave & 1 : wave; // 64-row sub-block
+    const int kg = KG == 2 ? wave / NRW : 0;  // key half of every 128-key tile this wave computes on
+    const int rw = KG == 2 ? wave % NRW : wave;  // row sub-block (WROWS rows)
     const int l31 = lane & 31, hi = lane >> 5;
 
     // ---- which (group, kv head, split, row block) ------------------------------------------
@@ -307,7 +420,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         }
         static_for<QB * NC>([&](auto I_) {
             constexpr int I = decltype(I_)::value;
-            QFrag<I>::template load<32 * (I % NC)>(qrow_p[I / NC]);
+            regs.template qload<I, 32 * (I % NC)>(qrow_p[I / NC]);
         });
     }
 
@@ -533,9 +646,9 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
             static_for<QB>([&](auto B_) __attribute__((always_inline)) {
                 constexpr int qb = decltype(B_)::value;
                 if constexpr (isqk) {
-                    if constexpr (QK) QFrag<qb * NC + idx>::template qk<BF, idx == 0>(Sw[qb], kfr[idx % PDK]);
+                    if constexpr (QK) regs.template qk<qb * NC + idx, BF, idx == 0>(Sw[qb], kfr[idx % PDK]);
                 } else {
-                    if constexpr (PV) OAcc<qb * NDB + idx % NDB>::template pv<BF>(vf, Pr[qb][idx / NDB]);
+                    if constexpr (PV) regs.template pv<qb * NDB + idx % NDB, BF>(vf, Pr[qb][idx / NDB]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int g0 = (j * NG) / NSLOT, g1 = ((j + 1) * NG) / NSLOT;
@@ -576,8 +689,20 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                     constexpr int i = j / EVERY;
                     if constexpr (i == 0) dma_m0(kdst[0] + kslot);
                     if constexpr (i == NLB) dma_m0(vdst[0] + vslot);
-                    if constexpr (i < NLB) dma16w<1024 * i, PERSIST>(krs, koffb[i], ksoff);
-                    else dma16w<1024 * (i - NLB), PERSIST>(vrs, voffb[i - NLB], vsoff);
+                    // ABL bit 13: every in-loop DMA re-reads block 0 (cache-hot source); bit 14: past the end (zero fill, no memory traffic)
+                    // bit 15 (timing only, wrong results): row block rb starts its key stream rb / row_blocks of the way in
+                    unsigned ks_ = (ABL & 8192) ? 0u : (ABL & 16384) ? 0x7fff0000u : ksoff;
+                    unsigned vs_ = (ABL & 8192) ? 0u : (ABL & 16384) ? 0x7fff0000u : vsoff;
+                    if constexpr ((ABL & 32768) != 0) {
+                        const unsigned tk = (unsigned)(nkeys & ~127) * k_ts2, tv = (unsigned)(nkeys & ~127) * v_ts2;
+                        const unsigned rot = (unsigned)rb * (unsigned)((nkeys / a.row_blocks) & ~127);
+                        ks_ += rot * k_ts2; vs_ += rot * v_ts2;
+                        if (ks_ >= tk) ks_ -= tk;
+                        if (vs_ >= tv) vs_ -= tv;
+                        ks_ = __builtin_amdgcn_readfirstlane(ks_); vs_ = __builtin_amdgcn_readfirstlane(vs_);
+                    }
+                    if constexpr (i < NLB) dma16w<1024 * i, PERSIST>(krs, koffb[i], ks_);
+                    else dma16w<1024 * (i - NLB), PERSIST>(vrs, voffb[i - NLB], vs_);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -592,10 +717,10 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
             for (int p = 0; p < PDV; ++p) { vfr[p][0] = ldv_at(p, 0, NVOFF); vfr[p][1] = ldv_at(p, 1, NVOFF); }
         }
         if constexpr (SM && !(ABL & 4)) {
-            if (pend) {  // cold: at most a handful of times per row block.  Every PV(i-1) MFMA has been issued: all of O
-                         // and l is still at the old reference and is rescaled exactly once; P(i) is at the new one.
-                acc_drain();
-                static_for<QB * NDB>([&](auto I_) { constexpr int I = decltype(I_)::value; OAcc<I>::scale(alpha[I / NDB]); });
+            // cold: at most a handful of times per row block.  Every PV(i-1) MFMA has been issued: all of O and l is still
+            // at the old reference and is rescaled exactly once; P(i) is at the new one.
+            regs.template rescale<QB, NDB>(pend, alpha);
+            if (pend) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) l_run[qb] *= alpha[qb];
             }
@@ -626,7 +751,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         dma_block(2, false);
         dma_block(0, true);
     }
-    static_for<QB * NDB>([&](auto I_) { OAcc<decltype(I_)::value>::zero(); });  // under the first loads' flight
+    static_for<QB * NDB>([&](auto I_) { regs.template zero<decltype(I_)::value>(); });  // under the first loads' flight
     stampk(1);
     if (NB > 0) dma_wait_w<3 * NLB>();
     else dma_wait_w<0>();
@@ -659,7 +784,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         kso += ((R) & 1) ? k_lo : k_hi;                                                                      \
         vso += ((R) & 1) ? v_lo : v_hi;                                                                      \
         kwv += ((R) & 1) ? 32 : (KG == 2 ? 96 : 32);                                                         \
-        dma_wait_w<2 * NLB>();                                                                               \
+        /* ABL bit 16 / 17 (timing only, racy): the barrier lets one / two more iterations' DMAs stay in flight */ \
+        dma_wait_w<((ABL & 131072) ? 6 : (ABL & 65536) ? 4 : 2) * NLB>();                                    \
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();                                                       \
     }
         int i0 = -1;
@@ -688,7 +814,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         dma_wait_w<0>();
         __syncthreads();  // nothing in flight, everyone done with the rings before the merge reuses them
     }
-    acc_drain();
+    regs.drain();
     stampk(3);
 #undef HYD_IC
 
@@ -701,13 +827,13 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     float l_tot[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) l_tot[qb] = pair_sum(l_run[qb]);
-    f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [4 waves][QB][HDB * 4][64 lanes] of f32x4 (64 KB at D = 128)
+    f32x4* obuf = reinterpret_cast<f32x4*>(smem);  // [NW waves][QB][HDB * 4][64 lanes] of f32x4 (64 KB at D = 128)
     if constexpr (KG == 2) {
         static_for<QB * HDB>([&](auto I_) __attribute__((always_inline)) {
             constexpr int qb = decltype(I_)::value / HDB, i = decltype(I_)::value % HDB;
             float ob[16];  // the d block this wave hands to its partner
-            if (kg) OAcc<qb * NDB + i>::read(ob);
-            else OAcc<qb * NDB + HDB + i>::read(ob);
+            if (kg) regs.template read<qb * NDB + i>(ob);
+            else regs.template read<qb * NDB + HDB + i>(ob);
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 f32x4 x = {ob[4 * q4], ob[4 * q4 + 1], ob[4 * q4 + 2], ob[4 * q4 + 3]};
@@ -722,7 +848,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         __syncthreads();
     }
     stampk(4);
-    const int pw = wave ^ 2;  // partner wave (KG = 2)
+    const int pw = wave ^ NRW;  // partner wave (KG = 2): same rows, other key half
     int lane_e = threadIdx.x & 31;
     asm volatile("" : "+v"(lane_e));  // opaque: the row decode below is recomputed, not kept live across the pipeline
     static_for<QB>([&](auto B_) __attribute__((always_inline)) {
@@ -750,8 +876,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         static_for<HDB>([&](auto D_) __attribute__((always_inline)) {
             constexpr int i = decltype(D_)::value;
             float ob[16];  // a d block this wave finalises
-            if (KG == 2 && kg) OAcc<qb * NDB + NDB - HDB + i>::read(ob);
-            else OAcc<qb * NDB + i>::read(ob);
+            if (KG == 2 && kg) regs.template read<qb * NDB + NDB - HDB + i>(ob);
+            else regs.template read<qb * NDB + i>(ob);
             const int db = KG == 2 ? kg * HDB + i : i;
             f32x4 x[4];
 #pragma unroll

@@ -13,8 +13,9 @@ CSRC = Path(__file__).resolve().parent.parent / "hydragen_amd" / "csrc"
 HIPCC = "/opt/rocm/bin/hipcc"
 # file -> (max VGPRs per kernel matching the regex)
 LIMITS = {
-    "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512)],   # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs)
-    "prefix_attn_w64_f16.hip": [(r"prefix_attn_w64_kernel", 512)],  # the fp16 instantiations of the same template
+    # 1 wave / SIMD: the unified count (VGPRs + 192 AGPRs); the 8-wave kernels (2 waves / SIMD) claim all 256 VGPRs of a wave
+    "prefix_attn_w64.hip": [(r"prefix_attn_w64_kernel", 512), (r"prefix_attn_w64x8_kernel", 256)],
+    "prefix_attn_w64_f16.hip": [(r"prefix_attn_w64_kernel", 512), (r"prefix_attn_w64x8_kernel", 256)],  # the fp16 instantiations
     # 2 waves / SIMD (two 8-KiB V tiles per wave bound the occupancy anyway); the count includes the 64 AGPRs of the K sets
     "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256)],
     "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\w+ELi\d+ELi1ELi1ELi\dE", 80)],  # <T, D, R = 1, WPU = 1, NPRE>, MHA decode: 6 waves / SIMD
@@ -76,10 +77,48 @@ def test_prefix_kernel_owns_its_accumulator_registers():
         elif not inasm and t and not t.startswith((";", ".", "//")) and re.search(r"\ba\[?\d", t.split(";")[0]):
             bad.append(t)
     assert not bad, bad[:5]
-    counts = [int(x) for x in re.findall(r"\.agpr_count:\s+(\d+)", out)]
+    counts = [int(blk.split()[0]) for blk in out.split("  - .agpr_count:")[1:]
+              if "prefix_attn_w64_kernel" in re.search(r"\.name:\s+(\S+)", blk).group(1)]
     assert counts and min(counts) >= 160, counts
     # (register numbers are assembler expressions of template constants; hipcc prints the larger ones in hex)
     assert "v_mfma_f32_32x32x16_bf16 a[0:15]" in out and "v_mfma_f32_32x32x16_f16 a[0:15]" in out and re.search(r"a\[(128|0x80):(131|0x83)\]", out)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_eight_wave_prefix_kernel_owns_the_top_of_the_register_file():
+    """The 8-wave prefix kernels (two waves per SIMD) keep O in the literal VGPRs v[160:223] and Q in v[224:255], named
+    only inside their asm statements (prefix_unit_w64.h, RegsV).  hipcc is kept below v160 by amdgpu_num_vgpr(80) on a
+    kernel that uses no accumulator register: no compiler-generated instruction may name v160 or above, the kernels
+    allocate no AGPR (hipcc would otherwise be held to 128 VGPRs and park values in accumulator registers), and the
+    descriptor covers the whole 256-register file."""
+    out = _device_asm("prefix_attn_w64.hip") + _device_asm("prefix_attn_w64_f16.hip")
+    kern, inasm, hi, agpr = None, False, {}, {}
+    for line in out.splitlines():
+        t = line.strip()
+        m = re.match(r"^(_ZN3hyd\w+):", t)
+        if m:
+            kern = m.group(1) if "w64x8" in m.group(1) else None
+            if kern:
+                hi[kern], agpr[kern] = -1, 0
+            continue
+        if kern is None:
+            continue
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
+        elif not inasm and t and not t.startswith((";", ".", "//")):
+            code = t.split(";")[0]
+            for mm in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", code):
+                hi[kern] = max(hi[kern], int(mm.group(2)) if mm.group(2) else int(mm.group(3)))
+            agpr[kern] += bool(re.search(r"\ba\[?\d", code))
+    assert len(hi) == 8, sorted(hi)  # {bf16, f16} x {dense, causal} x {128-row, 256-row workgroups}
+    for k in hi:
+        assert 0 <= hi[k] < 160 and agpr[k] == 0, (k, hi[k], agpr[k])
+    for blk in out.split("  - .agpr_count:")[1:]:
+        if "w64x8" in re.search(r"\.name:\s+(\S+)", blk).group(1):
+            assert int(blk.split()[0]) == 0 and int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) == 256, blk[:200]
+    assert re.search(r"v_mfma_f32_32x32x16_bf16 v\[(160|0xa0):(175|0xaf)\]", out) and re.search(r"v\[(224|0xe0):(227|0xe3)\]", out)
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")

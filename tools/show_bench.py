@@ -1,4 +1,9 @@
+"""Development tool: one-line summary of a bench.py JSON line.  `python tools/show_bench.py FILE` (or `-` for stdin)."""
 import json, sys
-d = json.loads(sys.stdin.read())
-print(sys.argv[1] if len(sys.argv) > 1 else "", {k: round(d[k], 1) for k in ("value", "attn_us_per_step", "prefix_us", "suffix_us_mean")},
-      "hbm_frac", round(d["roofline"]["frac"], 3), "mfma_frac", round(d["roofline_prefix"]["frac"], 3))
+if len(sys.argv) < 2:
+    sys.exit(__doc__)
+text = sys.stdin.read() if sys.argv[1] == "-" else open(sys.argv[1]).read()
+d = json.loads(text.strip().splitlines()[-1])
+other = d.get("roofline_other") or d.get("roofline_prefix") or {}
+print(sys.argv[1], {k: round(d[k], 1) for k in ("value", "attn_us_per_step", "prefix_us", "suffix_us_mean") if k in d},
+      "hbm_frac", round(d["roofline"]["frac"], 3), "mfma_frac", round(other.get("frac", 0.0), 3))
