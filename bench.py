@@ -58,6 +58,13 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_GBS = 6300.0  # measured streaming ceiling per /opt/skills/guides/MI355X_MICROARCH.md (79 % of spec)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
 SWEEP = (16, 32, 48, 64, 80, 96, 112, 128)  # docs/sweeps_from_paper.md:159-161 restricted to C2's 0..128
+# BASELINE.json configs that bench.py runs as a workload (the others are parity-test cases: tests/test_fullsize_gpu.py)
+WORKLOADS = {
+    "c2": dict(batch=1024, prefix=2048, max_suffix=128, qheads=32, kvheads=32,
+               name="C2 decode attention layer-step (Llama-2-7B head config)"),
+    "c5": dict(batch=2048, prefix=4096, max_suffix=256, qheads=64, kvheads=8,
+               name="C5 decode attention layer-step (Llama-3-70B head config, whole job: 64 q / 8 kv heads)"),
+}
 
 
 def parse():
@@ -65,12 +72,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--prefix", type=int, default=2048)
-    ap.add_argument("--max-suffix", type=int, default=128)
-    ap.add_argument("--qheads", type=int, default=32)
-    ap.add_argument("--kvheads", type=int, default=32)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="BASELINE.json config: c2 (the metric's: batch 1024, prefix 2048, 32/32 heads, suffix 1..128) or c5 "
+                         "(Llama-3-70B head config whole-job: batch 2048, prefix 4096, 64 q / 8 kv heads, suffix 1..256; "
+                         "sharded over heads at N > 1 as tp.py:90-124); --batch/--prefix/... override single fields")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--prefix", type=int, default=None)
+    ap.add_argument("--max-suffix", type=int, default=None)
+    ap.add_argument("--qheads", type=int, default=None)
+    ap.add_argument("--kvheads", type=int, default=None)
     ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--region-timeout", type=float, default=300.0,
+                    help="N > 1: seconds a rank waits inside the warm-up / timed region before it reports an error line and exits "
+                         "(a peer that never arrives must not hang the job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nosharing", action="store_true")
     ap.add_argument("--no-protocol", action="store_true", help="skip the graph + flush reference-protocol sweep")
@@ -88,7 +102,16 @@ def parse():
     ap.add_argument("--no-xgmi", action="store_true", help="N > 1: skip the direct xGMI all-reduce (hyd_allreduce_sum) leg")
     ap.add_argument("--no-graph-collective", action="store_true",
                     help="N > 1: skip the HIP-graph capture of (attention + all-reduce), llama.py:849-854")
-    return ap.parse_args()
+    return apply_workload(ap.parse_args())
+
+
+def apply_workload(args):
+    """Fill the shape fields a command line left unset from its --workload preset."""
+    w = WORKLOADS[args.workload]
+    for field, key in (("batch", "batch"), ("prefix", "prefix"), ("max_suffix", "max_suffix"), ("qheads", "qheads"), ("kvheads", "kvheads")):
+        if getattr(args, field) is None:
+            setattr(args, field, w[key])
+    return args
 
 
 def suffix_schedule(steps: int, smax: int) -> list[int]:
@@ -239,7 +262,7 @@ def main():
     sv = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
     sched = suffix_schedule(args.steps, S)
     warm_sched = suffix_schedule(max(args.warmup, 1), S)
-    sweep = [s for s in SWEEP if s <= S]
+    sweep = [s for s in SWEEP + (160, 192, 224, 256) if s <= S]
     ops = Ops(q, k, v, sk, sv, sched + warm_sched + sweep, two_stream=args.two_stream)
     for s_ in sorted(set(sched + warm_sched)):  # capture outside the timed region
         ops.graph(s_)
@@ -270,6 +293,9 @@ def main():
             collective()
             ev[3].record()
 
+    # N > 1: a rank that never arrives (a peer died, a collective that never completes) must end the job with an error
+    # line, not hang it: every rank arms a watchdog around the warm-up, the timed region and the repeats.
+    region_dog = _region_watchdog(args, rank, world) if world > 1 else None
     for i in range(args.warmup):
         step(warm_sched[i])
     torch.cuda.synchronize()
@@ -323,6 +349,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ = float(t.item())
         trial_us.append(dt_ / args.steps * 1e6)
+
+    if region_dog is not None:
+        region_dog.cancel()
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region ----------
     e = 2
@@ -379,10 +408,10 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"C2 decode attention layer-step: batch {B}, shared prefix {P}, {args.qheads}q/{args.kvheads}kv heads "
+            "workload": f"{WORKLOADS[args.workload]['name']}: batch {B}, shared prefix {P}, {args.qheads}q/{args.kvheads}kv heads "
                         f"d={D}, one hydragen_attention call per step at a fixed suffix length; suffix lengths of the timed "
                         f"steps: {describe_schedule(sched)}",
-            "batch": B, "prefix_len": P, "suffix_lens": sched if len(sched) <= 64 else describe_schedule(sched),
+            "preset": args.workload, "batch": B, "prefix_len": P, "suffix_lens": sched if len(sched) <= 64 else describe_schedule(sched),
             "suffix_len_mean": sum(sched) / len(sched), "qheads": args.qheads, "kvheads": args.kvheads, "head_dim": D,
             "parallelism": f"tp{world} (heads sharded, all-reduce [B,1,{hidden}] bf16 per step)" if world > 1 else "single GPU",
         },
@@ -431,7 +460,7 @@ def main():
         ops = q = k = v = sk = sv = None  # 2.3 GB of C2 tensors and the captured graphs: free them for the sweep's 18 GB
         torch.cuda.empty_cache()
         res["paper_sweep"] = _guarded(lambda: paper_sweep(max(4, args.protocol_iters // 3)), 120.0, res, rank, key="paper_sweep")
-    if solo and not args.no_model:
+    if solo and not args.no_model and args.workload == "c2":  # the model leg is Llama-2-7B at C2's batch and prefix
         ops = None
         torch.cuda.empty_cache()
         try:
@@ -527,6 +556,24 @@ def _attach_traffic(suffix_roof, prefix_roof, args, world):
             roof["traffic"] = b
         if t.get(f"{key}_algorithmic_bytes_per_launch"):
             roof["traffic_over_algorithmic"] = b / t[f"{key}_algorithmic_bytes_per_launch"]
+
+
+def _region_watchdog(args, rank, world):
+    """Timer that ends this rank with an error line when the warm-up / timed region of an N > 1 run does not finish in
+    --region-timeout seconds.  Every rank prints the line (a hung rank 0 cannot speak for the others); the exit code is
+    non-zero so that the launcher tears the other ranks down."""
+    def bail():
+        line = {"metric": "decode_attention_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "error": f"rank {rank}: the timed region did not finish within "
+                f"{args.region_timeout:.0f} s (a peer never arrived or a collective never completed)", "rank": rank}
+        print(json.dumps(line))
+        sys.stdout.flush()
+        os._exit(3)
+
+    timer = threading.Timer(args.region_timeout, bail)
+    timer.daemon = True
+    timer.start()
+    return timer
 
 
 def _guarded(fn, seconds, res, rank, key="graph_collective"):

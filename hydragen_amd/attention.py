@@ -122,8 +122,6 @@ def hydragen_attention(
         assert sk.shape == sv.shape, f"{sk.shape} {sv.shape}"
     _require_gpu(q, k, v, *shared_ks, *shared_vs, seq_lens)
     n_levels = len(shared_ks)
-    if n_levels > HYD_MAX_LEVELS:
-        raise NotImplementedError(f"at most {HYD_MAX_LEVELS} shared levels")
 
     b, nq, hq, d = q.shape
     dp = _flash.padded_head_dim(d)
@@ -141,11 +139,14 @@ def hydragen_attention(
     # seq_lens None means "causal over the unique part" in the reference (attention.py:343-345);
     # with a single query the bottom-right-aligned causal mask hides nothing, which is the decode case.
     fused_ok = seq_lens is not None or nq == 1 or k.shape[1] == 0
-    if fused_ok:
+    if fused_ok and n_levels <= HYD_MAX_LEVELS:
         return _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens,
                              use_varlens, seq_lens)
 
-    # unique-suffix prefill: per level prefix pass, causal MFMA pass over the unique K/V, N-way merge
+    # The general form, as the reference spells it for any number of levels (attention.py:250-352): one prefix pass per
+    # level, one pass over the unique K/V, an N-way log-sum-exp merge.  Taken for the unique-suffix prefill (causal
+    # MFMA pass over the unique K/V) and for hierarchies deeper than the one-call operator's HYD_MAX_LEVELS levels
+    # (decode: the suffix kernel with its LSE).  No host synchronisation: capture-safe like the one-call form.
     outs, lses = [], []
     for sk, sv, scu, smax, use_varlen in zip(shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens,
                                              use_varlens):
@@ -154,13 +155,50 @@ def hydragen_attention(
         lses.append(l)
     kvh = k.shape[2]
     assert k.shape[0] == b and hq % kvh == 0
-    uo, ul = prefix_attention(
-        q, k, v, sb=b, kv_len=k.shape[1], group_stride=(k.stride(0), v.stride(0)),
-        tok_stride=(k.stride(1), v.stride(1)), head_stride=(k.stride(2), v.stride(2)),
-        B=b, nq=nq, causal=True, lse_layout=HYD_LSE_BQH, lse_shape=(b, nq, hq),
-    )
-    outs.append(uo)
-    lses.append(ul)
+    if fused_ok:
+        if k.shape[1] > 0:
+            uo, ul = _flash.flash_attention_seqlen(q, k, v, seq_lens)
+            outs.append(uo)
+            lses.append(ul)
+    else:
+        uo, ul = prefix_attention(
+            q, k, v, sb=b, kv_len=k.shape[1], group_stride=(k.stride(0), v.stride(0)),
+            tok_stride=(k.stride(1), v.stride(1)), head_stride=(k.stride(2), v.stride(2)),
+            B=b, nq=nq, causal=True, lse_layout=HYD_LSE_BQH, lse_shape=(b, nq, hq),
+        )
+        outs.append(uo)
+        lses.append(ul)
+    return _combine_many(outs, lses)
+
+
+_COMBINE_MAX = 64  # partials one hyd_combine_lse launch merges (csrc/hyd_kernels.h kMaxCombine)
+
+
+def _combine_many(outs: list[Tensor], lses: list[Tensor]) -> Tensor:
+    """combine_lse for any number of partials: groups of at most _COMBINE_MAX are merged into (out, merged LSE) pairs
+    until one group is left (the merge is associative: attention.py:21-43)."""
+    while len(outs) > _COMBINE_MAX:
+        nouts, nlses = [], []
+        for i in range(0, len(outs), _COMBINE_MAX):
+            go, gl = outs[i:i + _COMBINE_MAX], lses[i:i + _COMBINE_MAX]
+            if len(go) == 1:
+                nouts.append(go[0])
+                nlses.append(gl[0])
+                continue
+            lib = _lib.load()
+            ref = go[0]
+            oc = [o.contiguous() for o in go]
+            lc = [l.contiguous().float() for l in gl]
+            res = torch.empty_like(oc[0])
+            rl = torch.empty(ref.shape[:-1], dtype=torch.float32, device=ref.device)
+            op = (C.c_void_p * len(oc))(*[o.data_ptr() for o in oc])
+            lp = (C.c_void_p * len(lc))(*[l.data_ptr() for l in lc])
+            dt = HYD_F32 if ref.dtype == torch.float32 else _dtype_code(ref)
+            _lib.check(lib.hyd_combine_lse(op, lp, len(oc), ref.numel() // ref.shape[-1], ref.shape[-1], dt,
+                                           res.data_ptr(), rl.data_ptr(), _stream()))
+            nouts.append(res)
+            nlses.append(rl)
+        outs, lses = nouts, nlses
     return combine_lse(outs, lses)
 
 

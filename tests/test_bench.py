@@ -58,6 +58,46 @@ def test_bench_two_ranks_without_a_launcher():
 
 
 @pytest.mark.gpu
+def test_bench_c5_workload_on_two_ranks():
+    """BASELINE config 5 as north_star states it (batch 2048, prefix 4096, 64 q / 8 kv heads, suffix 1..256), sharded over
+    heads on two ranks (32 q / 4 kv heads each, tp.py:90-124) with the 32 MiB [2048, 1, 8192] all-reduce per step."""
+    res = _run_bench(["--workload", "c5", "--gpus", "2", "--steps", "8", "--warmup", "2", "--trials", "1", "--cpu-seconds", "2",
+                      "--no-xgmi", "--no-accuracy"], {"HYD_BENCH_BACKEND": "gloo", "HYD_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["value"] > 0
+    assert cfg["preset"] == "c5" and cfg["batch"] == 2048 and cfg["prefix_len"] == 4096 and cfg["qheads"] == 64 and cfg["kvheads"] == 8
+    assert max(cfg["suffix_lens"]) <= 256 and "C5" in cfg["workload"] and "TP2" in cfg["parallelism"].upper()
+    assert res["allreduce_bytes"] == 2048 * 8192 * 2
+    for key in ("roofline", "roofline_other", "cpu_baseline"):
+        assert key in res, key
+    assert res["roofline"]["bound"] in ("hbm", "mfma") and 0 < res["roofline"]["frac"] < 1
+
+
+def test_workload_presets_and_overrides(monkeypatch):
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.workload, a.batch, a.prefix, a.max_suffix, a.qheads, a.kvheads) == ("c2", 1024, 2048, 128, 32, 32)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "c5", "--batch", "512"])
+    a = bench.parse()
+    assert (a.batch, a.prefix, a.max_suffix, a.qheads, a.kvheads) == (512, 4096, 256, 64, 8)
+
+
+def test_region_watchdog_prints_an_error_line_and_exits():
+    """A rank whose timed region never finishes (a peer that never arrives) leaves with an error line and a non-zero
+    exit code instead of hanging the job."""
+    code = ("import bench, sys, time, types\n"
+            "a = types.SimpleNamespace(steps=8, warmup=2, region_timeout=0.3)\n"
+            "bench._region_watchdog(a, 1, 2)\n"
+            "time.sleep(30)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=str(REPO))
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and "rank 1" in line["error"]
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line_is_complete():
     res = _run_bench(["--gpus", "1", "--steps", "8", "--warmup", "2", "--trials", "2", "--cpu-seconds", "2", "--no-model",
                       "--no-protocol"])

@@ -30,8 +30,48 @@ def test_eight_shared_levels():
     out = hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(x, dt) for x in sks], [dev(x, dt) for x in svs], dev(lens))
     torch.cuda.synchronize()
     assert_close(out.float().cpu().numpy(), O.hydragen_attention_nopad(q, k, v, sks, svs, lens), dt, "8 levels")
-    with pytest.raises(NotImplementedError):
-        hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(sks[0], dt)] * 9, [dev(svs[0], dt)] * 9, dev(lens))
+    # deeper hierarchies than the one-call operator's HYD_MAX_LEVELS run the general form (a prefix pass per level, the
+    # suffix kernel with its LSE, N-way merge): the reference loops over any number of levels (attention.py:250-341)
+    sbs12 = sbs + [16, 4, 2, 1]
+    sks12 = sks + [_rand(rng, (sb, 3 + i, Hkv, D), dt) for i, sb in enumerate(sbs12[8:])]
+    svs12 = svs + [_rand(rng, (sb, 3 + i, Hkv, D), dt) for i, sb in enumerate(sbs12[8:])]
+    want = O.hydragen_attention_nopad(q, k, v, sks12, svs12, lens)
+    out = hydragen_attention_nopad(dev(q, dt), dev(k, dt), dev(v, dt), [dev(x, dt) for x in sks12], [dev(x, dt) for x in svs12], dev(lens))
+    torch.cuda.synchronize()
+    assert_close(out.float().cpu().numpy(), want, dt, "12 levels")
+    # ... also inside a captured graph (no host synchronisation on that path), and with no unique keys at all
+    g = torch.cuda.CUDAGraph()
+    dq, dk, dv, dl = dev(q, dt), dev(k, dt), dev(v, dt), dev(lens)
+    dks, dvs = [dev(x, dt) for x in sks12], [dev(x, dt) for x in svs12]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hydragen_attention_nopad(dq, dk, dv, dks, dvs, dl)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            og = hydragen_attention_nopad(dq, dk, dv, dks, dvs, dl)
+    g.replay()
+    torch.cuda.synchronize()
+    assert_close(og.float().cpu().numpy(), want, dt, "12 levels, graph replay")
+    zl = np.zeros_like(lens)
+    out0 = hydragen_attention_nopad(dq, dk, dv, dks, dvs, dev(zl))
+    torch.cuda.synchronize()
+    assert_close(out0.float().cpu().numpy(), O.hydragen_attention_nopad(q, k, v, sks12, svs12, zl), dt, "12 levels, empty suffixes")
+
+
+def test_merge_of_more_partials_than_one_launch_takes():
+    """_combine_many: 70 partials are merged in groups (64 per launch) through (out, merged LSE) pairs."""
+    from hydragen_amd.attention import _combine_many
+
+    rng = np.random.default_rng(5)
+    n, shape = 70, (3, 2, 4, 64)
+    outs = [rng.standard_normal(shape).astype(np.float32) for _ in range(n)]
+    lses = [rng.standard_normal(shape[:-1]).astype(np.float32) * 3 for _ in range(n)]
+    got = _combine_many([torch.from_numpy(o).cuda() for o in outs], [torch.from_numpy(l).cuda() for l in lses])
+    torch.cuda.synchronize()
+    L = np.stack(lses).astype(np.float64)
+    w = np.exp(L - L.max(0))
+    want = (np.stack(outs).astype(np.float64) * w[..., None]).sum(0) / w.sum(0)[..., None]
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])

@@ -31,6 +31,7 @@ CONFIGS = [
     ("C3 (B=64,P=16384,S=256,32/8)", 64, [(1, 16384)], 256, 32, 8, 128, torch.bfloat16),
     ("C4 two-level (1x1024 + 32x64, B=1024,S=32)", 1024, [(1, 1024), (32, 64)], 32, 32, 32, 128, torch.bfloat16),
     ("C5 TP=8 slice (B=2048,P=4096,S=256,8/1)", 2048, [(1, 4096)], 256, 8, 1, 128, torch.bfloat16),
+    ("C5 whole job (B=2048,P=4096,S=256,64/8)", 2048, [(1, 4096)], 256, 64, 8, 128, torch.bfloat16),
     ("paper sweep corner (B=32,P=1024,S=128,8/1)", 32, [(1, 1024)], 128, 8, 1, 128, torch.bfloat16),
     ("paper sweep corner (B=2048,P=16256,S=128,8/1)", 2048, [(1, 16256)], 128, 8, 1, 128, torch.bfloat16),
 ]
