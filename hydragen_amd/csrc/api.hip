@@ -597,6 +597,7 @@ constexpr int64_t kSingleLaunchMaxKeys = 8192;
 static bool decode_runs_as_one_launch(const hyd_decode_params* p, const hyd_prefix_params* pps, const PrefixPlan* pls, const bool* small) {
     const hyd_suffix_params& sp = p->suffix;
     if (p->phase != HYD_PHASE_ALL || !p->single_launch_small || p->n_levels != 1 || !small[0] || sp.kv_len <= 0) return false;
+    if (sp.lse) return false;  // suffix.lse is the LSE of the unique keys alone in every form; one walk over both segments cannot give it
     const hyd_prefix_params& pp = pps[0];
     if (pp.cu_seqlens_k || pp.sb <= 0 || sp.B % pp.sb != 0) return false;  // (a small level runs unsplit whatever the plan says)
     if (pp.k_tok_stride != sp.k_tok_stride || pp.v_tok_stride != sp.v_tok_stride) return false;
@@ -706,6 +707,7 @@ size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32
     p.suffix.Hkv = Hkv;
     p.suffix.D = D;
     p.suffix.kv_len = 1;  // a decode step has unique keys: size the unique partial of the two-stream form as well
+    p.f32_partials = 1;   // an upper bound for every form of the call: an unsplit level's partial may be kept in fp32
     p.n_levels = n_levels;
     for (int i = 0; i < n_levels; ++i) {
         p.levels[i].sb = level_sb[i];
@@ -776,6 +778,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         a.pv_gs = pps[0].v_group_stride; a.pv_hs = pps[0].v_head_stride;
         a.p_len = pps[0].kv_len;
         a.p_per = sp.B / pps[0].sb;
+        a.shared_kv = 1;  // p_per sequences read the same prefix keys: default cache policy, not the read-once hint
         rc = launch_suffix_gqa(a, sp.dtype, sp.D, s);
         return rc ? fail(HYD_ERR_LAUNCH, "single-launch decode kernel failed: hip error %d", rc) : HYD_OK;
     }

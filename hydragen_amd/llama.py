@@ -75,7 +75,11 @@ class RMSNorm(nn.Module):
 
     def forward(self, x):
         # one fused kernel (fp32 statistics inside) instead of the seven elementwise / reduce launches of the spelled-out
-        # form (float, pow, mean, add + rsqrt, mul, cast, mul): 2 norms x 32 layers of them were 13 % of a decode step
+        # form (float, pow, mean, add + rsqrt, mul, cast, mul): 2 norms x 32 layers of them were 13 % of a decode step.
+        # Deviation from transformers' LlamaRMSNorm (stated): that one rounds x * rsqrt(var + eps) to the
+        # 16-bit dtype BEFORE the multiply by `weight`; this form (and hyd_add_rmsnorm, csrc/layer_ops.hip) multiplies in
+        # fp32 and rounds once -- at most one 16-bit ulp per element apart, the closer of the two to the fp32 formula
+        # (tests/test_layer_ops_gpu.py bounds both against it).
         return nn.functional.rms_norm(x, (x.shape[-1],), self.weight, self.variance_epsilon)
 
 
@@ -84,11 +88,22 @@ def _fused_weight(cache: Optional[Tensor], linears) -> Optional[Tensor]:
     input (q|k|v, gate|up): the decode step then runs one GEMM instead of two or three (MI355X, batch 1024, Llama-2-7B:
     129 -> 86 us for q, k, v and 167 -> 154 us for gate, up per layer; tests/probes/gemm_fusion_probe.py).  The modules'
     own `weight` parameters become VIEWS of the fused tensor, so state dicts, in-place loading, `make_tp_files` and the
-    reference's attribute names keep working and no memory is added; anything that replaces a weight (`apply_tp`, `.to()`)
-    is noticed by its address and fused again.  None when it does not apply (biases, meta / CPU weights, graph capture)."""
+    reference's attribute names keep working and no memory is added; anything that replaces ANY of the weights (`apply_tp`,
+    `.to()`, a quantised or merged single projection) is noticed by its address and everything is fused again.  The shared
+    storage means that a per-tensor ownership check (safetensors `save_file`) sees aliases: save `state_dict()` clones or
+    call `unfuse_weights(model)` first.  None when it does not apply (biases, meta / CPU weights, graph capture)."""
     w0 = linears[0].weight
-    if cache is not None and w0.data_ptr() == cache.data_ptr() and w0.shape[1] == cache.shape[1]:
-        return cache
+    if cache is not None and w0.shape[1] == cache.shape[1]:
+        # every module's weight must still BE its slice of the fused tensor: any of them may have been replaced on its own
+        # (quantisation, a LoRA merge, load_state_dict(assign=True) on part of the modules)
+        off, row = cache.data_ptr(), cache.shape[1] * cache.element_size()
+        for l in linears:
+            if l.weight.data_ptr() != off or l.weight.dtype != cache.dtype or not l.weight.is_contiguous():
+                break
+            off += l.weight.shape[0] * row
+        else:
+            if off == cache.data_ptr() + cache.shape[0] * row:
+                return cache
     if any(l.bias is not None for l in linears) or not w0.is_cuda or torch.cuda.is_current_stream_capturing():
         return None
     with torch.no_grad():
@@ -99,6 +114,17 @@ def _fused_weight(cache: Optional[Tensor], linears) -> Optional[Tensor]:
             l.weight.data = w[o:o + n]
             o += n
     return w
+
+
+def unfuse_weights(module: nn.Module) -> None:
+    """Give every projection its own storage again (undoes `_fused_weight` until the next forward fuses anew)."""
+    for m in module.modules():
+        for attr, names in (("_gate_up", ("gate_proj", "up_proj")), ("_qkv", ("q_proj", "k_proj", "v_proj"))):
+            if getattr(m, attr, None) is not None:
+                for n in names:
+                    lin = getattr(m, n)
+                    lin.weight.data = lin.weight.data.clone()
+                setattr(m, attr, None)
 
 
 class LlamaMLP(nn.Module):
@@ -638,17 +664,33 @@ class HydragenLlamaForCausalLM(nn.Module):
         return self.config.num_attention_heads
 
     def setup_caches(self, max_unique_batch_size: int, max_unique_seq_length: int,
-                     max_shared_batch_sizes: list[int], max_shared_seq_lengths: list[int]):
-        """Allocate the unique KV cache and the shared cache levels at every layer (llama.py:921-955)."""
+                     max_shared_batch_sizes: list[int], max_shared_seq_lengths: list[int],
+                     timing_only_alias_unique_cache: bool = False):
+        """Allocate the unique KV cache and the shared cache levels at every layer (llama.py:921-955).
+
+        timing_only_alias_unique_cache (not in the reference; bench.py's no-sharing leg): every layer's unique K/V cache is
+        ONE pair of buffers.  The generated tokens are meaningless then (the layers overwrite each other's keys), the time
+        per step is not: every layer still appends to and streams the whole buffer from HBM.  It is what lets the
+        no-sharing baseline (scripts/synth.py:112,151: the prefix replicated into every sequence's cache, 36 GB per LAYER at
+        batch 1024 / prefix 2048) run at the batch the headline is quoted on."""
         self.maybe_invalidate()
         max_unique_seq_length = (max_unique_seq_length + 15) // 16 * 16
+        first = None
         for layer in self.model.layers:
-            layer.self_attn.kv_cache = PerLayerKVCache(
-                max_unique_batch_size=max_unique_batch_size, max_unique_seq_length=max_unique_seq_length,
+            alias = timing_only_alias_unique_cache and first is not None
+            cache = PerLayerKVCache(
+                max_unique_batch_size=1 if alias else max_unique_batch_size,
+                max_unique_seq_length=16 if alias else max_unique_seq_length,
                 max_shared_batch_sizes=max_shared_batch_sizes, max_shared_seq_lengths=max_shared_seq_lengths,
                 n_kv_heads=self.config.num_key_value_heads,
                 head_dim=self.config.hidden_size // self.get_num_heads(),
                 device=self.lm_head.weight.device, dtype=self.lm_head.weight.dtype)
+            if alias:
+                cache.per_completion_k_cache = first.per_completion_k_cache
+                cache.per_completion_v_cache = first.per_completion_v_cache
+            elif first is None:
+                first = cache
+            layer.self_attn.kv_cache = cache
         self.kv_cache_allocated = True
 
     def empty_shared_cache(self):

@@ -189,7 +189,8 @@ typedef struct hyd_decode_params {
                                     * few keys in all -- runs as ONE kernel that walks the group's shared keys and then
                                     * the sequence's own (what the no-sharing baseline does, without the replicated
                                     * prefix).  The result then differs from the phase-split forms by their roundings of
-                                    * the partial.  0: always the prefix pass + suffix pass pair.                    */
+                                    * the partial.  Not taken when suffix.lse is set (that is the LSE of the unique
+                                    * keys alone in every form).  0: always the prefix pass + suffix pass pair.       */
     int32_t reserved;
 } hyd_decode_params;
 
@@ -199,7 +200,8 @@ HYD_API int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream);
 HYD_API int hyd_decode_two_stream_ok(const hyd_decode_params* p);
 
 /* Upper bound helper mirroring SURVEY 8b's `hyd_workspace_bytes(shape...)`: bytes that
- * hyd_decode_attn_fused needs for n_levels uniform levels of the given shapes. */
+ * hyd_decode_attn_fused needs for n_levels uniform levels of the given shapes, in ANY form of the
+ * call (every phase, f32_partials set or not: unsplit levels are sized with fp32 partials). */
 HYD_API size_t hyd_workspace_bytes(int32_t B, int32_t nq, int32_t Hq, int32_t Hkv, int32_t D, int32_t n_levels,
                            const int32_t* level_sb, const int32_t* level_kv_len);
 

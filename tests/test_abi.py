@@ -122,10 +122,20 @@ def test_decode_workspace_accounting():
     sb = (C.c_int32 * 2)(1, 32)
     ln = (C.c_int32 * 2)(1024, 64)
     rows = 1024 * 32
-    # C4: two levels, both fill the chip -> one bf16 slice + one fp32 LSE vector per level, + the same for the unique
-    # pass's own partial (two-stream form)
-    want = 3 * (rows * 128 * 2 + rows * 4)
+    # C4: two levels, both fill the chip -> one partial + one fp32 LSE vector per level, + a 16-bit partial and an LSE
+    # vector for the unique pass's own (two-stream form).  The shape helper is an upper bound for every form of the call,
+    # f32_partials included: the levels' partials are sized in fp32.
+    want = 2 * (rows * 128 * 4 + rows * 4) + (rows * 128 * 2 + rows * 4)
     assert lib.hyd_workspace_bytes(1024, 1, 32, 32, 128, 2, sb, ln) == want
+    d = DecodeParams()
+    d.suffix.dtype, d.suffix.B, d.suffix.nq, d.suffix.Hq, d.suffix.Hkv, d.suffix.D, d.suffix.kv_len = 1, 1024, 1, 32, 32, 128, 16
+    d.n_levels = 2
+    for i, (b_, l_) in enumerate(((1, 1024), (32, 64))):
+        d.levels[i].sb, d.levels[i].kv_len = b_, l_
+    for f32 in (0, 1):
+        d.f32_partials = f32
+        assert lib.hyd_decode_workspace_bytes(C.byref(d)) <= want
+    assert lib.hyd_decode_workspace_bytes(C.byref(d)) == want  # f32_partials = 1: exactly the bound
     d = DecodeParams()
     d.suffix.dtype, d.suffix.B, d.suffix.nq, d.suffix.Hq, d.suffix.Hkv, d.suffix.D = 1, 1024, 1, 32, 32, 128
     d.n_levels = 9

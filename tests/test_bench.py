@@ -104,7 +104,10 @@ def test_bench_single_gpu_line_is_complete():
     assert res["n_gpus"] == 1 and res["metric"] == "decode_attention_tokens_per_sec" and res["unit"] == "tokens/s"
     assert res["vs_baseline"] is None and res["dtype"] == "bf16" and res["data"] == "synthetic"
     assert len(res["trials"]["repeat_us_per_step"]) == 2
-    assert abs(res["trials"]["trial0_us_per_step"] - res["ms_per_step"] * 1e3) < 1e-6
+    assert abs(res["trials"]["trial0_us_per_step"] / (res["ms_per_step"] * 1e3) - 1) < 1e-4  # (nested figures carry 5 digits)
+    assert len(json.dumps(res)) < 8000 and res["detail_file"] == "profiles/bench_detail_latest.json"  # the driver keeps 8 KB
+    detail = json.loads((REPO / res["detail_file"]).read_text())
+    assert detail["value"] == res["value"] and "trials" in detail and "roofline_other" in detail
     assert set(res["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(res["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample", "c1_full"}
     # HBM bytes per launch are counted in the run itself (rocprofv3 --pmc child passes), for both kernels
@@ -149,3 +152,39 @@ def test_two_stream_policy_is_shapes_only():
         assert A._want_two_stream(*args, capturing=False)
     finally:
         A.set_two_stream(prev)
+
+
+def test_compact_line_fits_the_drivers_record(tmp_path, monkeypatch):
+    """The driver keeps the last 8 KB of bench.py's line: the line carries means at five digits, the per-point statistics
+    and the prose go to profiles/bench_detail_latest.json (round 3's 17 KB line lost roofline_other / trials / prefix_us)."""
+    import bench
+
+    monkeypatch.setattr(bench, "DETAIL_FILE", tmp_path / "detail.json")
+    monkeypatch.setattr(bench, "REPO", tmp_path)
+    stat = lambda m: {"mean_us": m * 1.000001234, "std_us": 1.23456789, "rstd": 0.0123456789, "n": 20}
+    cols = ("hydragen_flushed", "hydragen_flushed_clean", "hydragen_back_to_back", "two_stream_flushed_clean",
+            "two_stream_back_to_back", "nosharing_flushed")
+    res = {
+        "metric": "decode_attention_tokens_per_sec", "value": 4604443.873278889, "unit": "tokens/s", "ms_per_step": 0.2223938499810174,
+        "config": {"workload": "w" * 250, "suffix_lens": list(range(20))},
+        "roofline": {"frac": 0.7682519848229409, "traffic_source": "counted in this run: " + "x" * 300},
+        "roofline_other": {"frac": 0.3338571052407633, "traffic_source": "counted in this run: " + "y" * 300},
+        "trials": {"repeat_us_per_step": [219.81835016049445, 221.13814920885488], "headline": "h" * 60, "repeat_note": "n" * 90},
+        "reference_protocol": {"protocol": "p" * 700, "iters": 20,
+                               "by_suffix_len": {str(s): dict({c: stat(100.0 + s) for c in cols}, speedup=25.123456789) for s in range(16, 129, 16)}},
+        "paper_sweep": {"rows": [{"batch": 512 * (1 + i // 3), "prefix": 1024, "suffix": 128 * (i % 3), "hydragen_us": 28.146833181381226,
+                                  "hydragen_rstd": 0.0255, "nosharing_us": 60.14766792456309, "speedup": 2.136924873109704} for i in range(12)]},
+        "events": {"steps": list(range(64)), "why": "e" * 170},
+        "cpu_baseline": {"value": 1030.123456, "sample": "s" * 207},
+        "accuracy": {f"k{i}": 0.001234567891 * i for i in range(30)},
+    }
+    line = bench.compact_line(res)
+    text = json.dumps(line)
+    assert len(text) < 8000, len(text)
+    assert line["value"] == res["value"] and line["ms_per_step"] == res["ms_per_step"]
+    assert line["roofline"]["frac"] == 0.76825 and line["trials"]["repeat_us_per_step"] == [219.82, 221.14]
+    by = line["reference_protocol"]["by_suffix_len"]
+    assert by["columns"][-1] == "speedup" and len(by["mean_us"]["16"]) == len(cols) + 1 and by["mean_us"]["16"][-1] == 25.123
+    assert line["paper_sweep"]["rows"]["columns"][:3] == ["batch", "prefix", "suffix"] and len(line["paper_sweep"]["rows"]["values"]) == 12
+    full = json.loads((tmp_path / "detail.json").read_text())
+    assert full["reference_protocol"]["by_suffix_len"]["16"]["hydragen_flushed"]["n"] == 20 and full["roofline"]["frac"] == res["roofline"]["frac"]

@@ -370,3 +370,28 @@ def test_fused_layer_glue_equals_the_spelled_out_layers(dtype):
     l2 = (d.norm() / plain.float().norm()).item()
     assert l2 <= (2.0e-2 if dtype == torch.bfloat16 else 2.5e-3), l2
     assert d.abs().max().item() <= (3.0e-2 if dtype == torch.bfloat16 else 4.0e-3) * scale, (d.abs().max().item(), scale)
+
+
+def test_fused_projection_weights_follow_a_replaced_projection():
+    """the q | k | v and gate | up GEMMs read one fused weight of which the modules' weights are views.
+    Replacing ONE projection later (a quantised / merged k_proj, up_proj) must not leave the stale fused tensor in use, and
+    unfuse_weights() gives every projection its own storage back."""
+    from hydragen_amd.llama import unfuse_weights
+
+    torch.manual_seed(3)
+    model = make_model(torch.bfloat16, layers=1)
+    layer = model.model.layers[0]
+    x = torch.randn(4, 1, model.config.hidden_size, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        y0 = layer.mlp(x)
+        assert layer.mlp._gate_up is not None and layer.mlp.up_proj.weight.data_ptr() != layer.mlp._gate_up.data_ptr()
+        assert layer.mlp.gate_proj.weight.data_ptr() == layer.mlp._gate_up.data_ptr()
+        layer.mlp.up_proj.weight.data = torch.zeros_like(layer.mlp.up_proj.weight)  # replaced on its own: silu(g) * 0 = 0
+        y1 = layer.mlp(x)
+        assert float(y1.abs().max()) == 0.0 and float(y0.abs().max()) > 0.0
+        assert layer.mlp.up_proj.weight.data_ptr() == layer.mlp._gate_up.data_ptr() + layer.mlp.gate_proj.weight.numel() * 2  # fused again
+        unfuse_weights(model)
+        assert layer.mlp._gate_up is None
+        ptrs = {layer.mlp.gate_proj.weight.untyped_storage().data_ptr(), layer.mlp.up_proj.weight.untyped_storage().data_ptr()}
+        assert len(ptrs) == 2
+        assert float(layer.mlp(x).abs().max()) == 0.0
