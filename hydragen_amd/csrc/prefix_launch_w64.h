@@ -11,9 +11,24 @@ namespace hyd {
 // to a part of the chip) -- persistent workgroups that walk the units with a stride of the grid.  Two instantiations on
 // purpose: wrapped in the unit loop, the body's loop-invariant scalars are hoisted and spilled to VGPR lanes, which
 // costs the one-unit launch 1-3 % (A/B against the round-2 library, tests/probes/ab_r2_prefix.py).
+// The kernel's 248 bytes of arguments span four 64-byte lines of the scalar cache, and hipcc fetches fields where it first
+// needs them: three of those fetches are misses that wait for one another before the first global load is issued (the
+// row decode needs fields of every line).  Touch every line at once, first thing: one miss time instead of three.
+__device__ __forceinline__ void warm_kernargs() {
+    static_assert(sizeof(PrefixArgs) <= 256, "four scalar-cache lines");
+    const void* ka = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t0, t1, t2, t3;
+    // the loads stay in flight beside hipcc's own first argument fetches; the registers stay claimed until the wait below
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
+                 : "={s96}"(t0), "={s97}"(t1), "={s98}"(t2), "={s99}"(t3)  // (not registers hipcc's first fetches are landing in)
+                 : "s"(ka));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+{s96}"(t0), "+{s97}"(t1), "+{s98}"(t2), "+{s99}"(t3));
+}
+
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    warm_kernargs();
     if constexpr (!PERSIST) {
         prefix_unit_w64<T, D, CAUSAL, KG, ABL, false, 4>(a, blockIdx.x, a.vgrid, smem);
     } else {
@@ -30,6 +45,7 @@ __global__ __launch_bounds__(256) void prefix_attn_w64_kernel(const PrefixArgs a
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(80))) void prefix_attn_w64x8_kernel(const PrefixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    warm_kernargs();
     prefix_unit_w64<T, D, CAUSAL, KG, ABL, false, 8>(a, blockIdx.x, a.vgrid, smem);
 }
 

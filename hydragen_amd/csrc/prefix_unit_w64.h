@@ -278,8 +278,30 @@ constexpr int kElemOps[54] = {
     HYD_OP(2, 7), HYD_OP(4, 6), HYD_OP(3, 7),                // g14
     HYD_OP(5, 6), HYD_OP(6, 6), HYD_OP(4, 7), HYD_OP(5, 7), HYD_OP(6, 7),  // g15  (no exp2 left: nothing here reads a result of its own group)
 };
-#undef HYD_OP
 constexpr int kElemGroupStart[15] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 39, 42, 46, 49, 54};
+// The same 54 operations for the 8-wave unit's softmax, which has no maximum tree in front (see LAZY in the iteration): all
+// 16 groups carry element work, 4 / 5 issue slots alternating, every consumer at least one group behind its producer, at
+// most six exponentials alive at a time (list-scheduled, tools-free: the rule is in the comment of kElemOps).
+constexpr int kElemOpsL[54] = {
+    HYD_OP(0, 0), HYD_OP(1, 0), HYD_OP(0, 1), HYD_OP(1, 1),                // g0
+    HYD_OP(0, 2), HYD_OP(2, 0), HYD_OP(3, 0),                              // g1
+    HYD_OP(6, 0), HYD_OP(2, 1), HYD_OP(1, 2),                              // g2
+    HYD_OP(4, 1), HYD_OP(3, 1), HYD_OP(2, 2),                              // g3
+    HYD_OP(6, 1), HYD_OP(3, 2), HYD_OP(5, 1),                              // g4
+    HYD_OP(6, 2), HYD_OP(4, 2), HYD_OP(5, 2), HYD_OP(0, 3), HYD_OP(1, 3),  // g5
+    HYD_OP(2, 3), HYD_OP(3, 3),                                            // g6
+    HYD_OP(6, 3), HYD_OP(4, 3), HYD_OP(5, 3), HYD_OP(0, 4), HYD_OP(1, 4),  // g7
+    HYD_OP(2, 4), HYD_OP(3, 4),                                            // g8
+    HYD_OP(6, 4), HYD_OP(4, 4), HYD_OP(5, 4), HYD_OP(0, 5), HYD_OP(1, 5),  // g9
+    HYD_OP(2, 5), HYD_OP(3, 5),                                            // g10
+    HYD_OP(6, 5), HYD_OP(4, 5), HYD_OP(5, 5), HYD_OP(0, 6), HYD_OP(1, 6),  // g11
+    HYD_OP(2, 6), HYD_OP(3, 6),                                            // g12
+    HYD_OP(6, 6), HYD_OP(4, 6), HYD_OP(5, 6), HYD_OP(0, 7), HYD_OP(1, 7),  // g13
+    HYD_OP(2, 7), HYD_OP(3, 7),                                            // g14
+    HYD_OP(6, 7), HYD_OP(4, 7), HYD_OP(5, 7),                              // g15
+};
+constexpr int kElemGroupStartL[17] = {0, 4, 7, 10, 13, 16, 21, 23, 28, 30, 35, 37, 42, 44, 49, 51, 54};
+#undef HYD_OP
 
 }  // namespace
 
@@ -500,6 +522,13 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     // Online-softmax state per query block, in RAW score units (before the scale): the reference maximum m_raw (equal in
     // the two lanes of a row), nms = -sc * m_raw and the threshold thr = m_raw + kTau / sc above which a block's lane
     // maximum forces a new reference.  kMinit is a finite "minus infinity": exp2(sc * (m_old - m_new)) never sees inf - inf.
+    // LAZY (the 8-wave unit): no maximum tree in the hot path at all.  A block's probabilities are computed against the
+    // reference as it stands; if any lane's 16 of them sum to more than 2^kTau (which also catches an overflow to inf, and
+    // -- nms starts at +1e30 sc -- the first valid key of a row), the wave takes the cold branch: true block maximum, new
+    // reference = max(old, block), the block's probabilities recomputed from the raw scores (which the hot path leaves
+    // intact: its fma / exp2 work on temporaries), O and l rescaled at the end of the iteration as before.  Below the
+    // threshold every probability is <= its lane's sum <= 2^kTau: the same bound the threshold on the maximum gives.
+    constexpr bool LAZY = NW == 8;
     constexpr float kMinit = -1.0e30f;
     float m_raw[QB], nms[QB], thr[QB], l_run[QB];
     f32x16 S0[QB], S1[QB];
@@ -508,7 +537,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     for (int qb = 0; qb < QB; ++qb) {
         m_raw[qb] = kMinit;
         thr[qb] = kMinit;
-        nms[qb] = 0.f;
+        nms[qb] = LAZY ? -kMinit * a.scale_log2e : 0.f;  // LAZY: exp2(score + huge) = inf trips the sum test at the row's first valid key
         l_run[qb] = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) S0[qb][i] = S1[qb][i] = 0.f;
@@ -588,12 +617,26 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         //         O / l rescale executed -- the hot path never touches m, nms or alpha.
         //   g2-g15: 54 element operations in the order of kElemOps, five issue slots per group (scalar f32 ops on purpose: packed
         //         f32 VALU beside MFMAs costs more than the two scalar instructions it replaces).
+        float Y[QB][16];  // LAZY: the block's scaled scores, then probabilities (the raw scores stay in Sr for the cold branch)
         auto elem_op = [&](auto K_, int qb) __attribute__((always_inline)) {
             f32x16& S = Sr[qb];
-            constexpr int code = kElemOps[decltype(K_)::value];
+            constexpr int code = LAZY ? kElemOpsL[decltype(K_)::value] : kElemOps[decltype(K_)::value];
             constexpr int kind = code >> 3, pr = code & 7, e0 = 2 * pr, e1 = 2 * pr + 1;
             if constexpr ((ABL & 64) || ((ABL & 32) && (kind == 2 || kind == 3)) || ((ABL & 128) && kind >= 4))
                 return;
+            else if constexpr (LAZY) {
+                float(&y)[16] = Y[qb];
+                if constexpr (kind == 0) { y[e0] = __builtin_fmaf(S[e0], sc, nms[qb]); asm volatile("" : "+v"(y[e0])); }
+                else if constexpr (kind == 1) { y[e1] = __builtin_fmaf(S[e1], sc, nms[qb]); asm volatile("" : "+v"(y[e1])); }
+                else if constexpr (kind == 2) { y[e0] = fast_exp2(y[e0]); asm volatile("" : "+v"(y[e0])); }
+                else if constexpr (kind == 3) { y[e1] = fast_exp2(y[e1]); asm volatile("" : "+v"(y[e1])); }
+                else if constexpr (kind == 4) { if constexpr (pr == 1) su0[qb] = y[0] + y[2]; else su0[qb] += y[e0]; asm volatile("" : "+v"(su0[qb])); }
+                else if constexpr (kind == 5) { if constexpr (pr == 1) su1[qb] = y[1] + y[3]; else su1[qb] += y[e1]; asm volatile("" : "+v"(su1[qb])); }
+                else {
+                    Pw[qb][pr >> 2][pr & 3] = TR::pack2(y[e0], y[e1]);
+                    asm volatile("" ::"v"(Pw[qb][pr >> 2][pr & 3]));
+                }
+            }
             else if constexpr (kind == 0) { S[e0] = __builtin_fmaf(S[e0], sc, nms[qb]); asm volatile("" : "+v"(S[e0])); }
             else if constexpr (kind == 1) { S[e1] = __builtin_fmaf(S[e1], sc, nms[qb]); asm volatile("" : "+v"(S[e1])); }
             else if constexpr (kind == 2) { S[e0] = fast_exp2(S[e0]); asm volatile("" : "+v"(S[e0])); }
@@ -608,7 +651,12 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         };
         auto valu_group = [&](auto G_, int qb) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value;
-            if constexpr (SM && !(ABL & 4)) {
+            if constexpr (SM && !(ABL & 4) && LAZY) {
+                constexpr int k0 = kElemGroupStartL[g], k1 = kElemGroupStartL[g + 1];
+                static_for<k1 - k0>([&](auto K_) __attribute__((always_inline)) {
+                    elem_op(std::integral_constant<int, k0 + decltype(K_)::value>{}, qb);
+                });
+            } else if constexpr (SM && !(ABL & 4)) {
                 f32x16& S = Sr[qb];
                 if constexpr (g == 0) {
                     t0[qb] = fmaxf(fmaxf(S[0], S[1]), S[2]);
@@ -657,7 +705,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (SM && !(ABL & 4) && (j * NG) / NSLOT <= 1 && 1 < ((j + 1) * NG) / NSLOT) {
+            if constexpr (SM && !(ABL & 4) && !LAZY && (j * NG) / NSLOT <= 1 && 1 < ((j + 1) * NG) / NSLOT) {
                 // both query blocks know their lane maxima: adopt a new reference maximum?  (cold, wave-uniform)
                 if ((upb[0] | upb[QB - 1]) != 0ull) {
                     asm volatile("" ::: "memory");  // keep this a branch
@@ -715,6 +763,33 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         if constexpr (NPVF) {
 #pragma unroll
             for (int p = 0; p < PDV; ++p) { vfr[p][0] = ldv_at(p, 0, NVOFF); vfr[p][1] = ldv_at(p, 1, NVOFF); }
+        }
+        if constexpr (SM && !(ABL & 4) && LAZY) {
+            static_assert(!LAZY || QB == 1, "the 8-wave unit runs one query block per wave");
+            const float bsum = su0[0] + su1[0];
+            if (__builtin_amdgcn_ballot_w64(bsum > 256.0f /* 2^kTau */) != 0ull) {  // cold, wave-uniform
+                asm volatile("" ::: "memory");  // keep this a branch
+                f32x16& S = Sr[0];
+                float tm = fmaxf(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])), fmaxf(fmaxf(S[4], S[5]), fmaxf(S[6], S[7])));
+                tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(S[8], S[9]), fmaxf(S[10], S[11])), fmaxf(fmaxf(S[12], S[13]), fmaxf(S[14], S[15]))));
+                tm = pair_max(tm);                            // the row's maximum: both lanes of a row decide alike
+                const float newm = fmaxf(tm, m_raw[0]);       // (tm = -inf: every key of the block masked for this row)
+                alpha[0] = fast_exp2((m_raw[0] - newm) * sc);
+                m_raw[0] = newm;
+                nms[0] = -newm * sc;
+                float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr) {
+                    const float pa = fast_exp2(__builtin_fmaf(S[2 * pr], sc, nms[0]));
+                    const float pb = fast_exp2(__builtin_fmaf(S[2 * pr + 1], sc, nms[0]));
+                    r0 += pa;
+                    r1 += pb;
+                    Pw[0][pr >> 2][pr & 3] = TR::pack2(pa, pb);
+                }
+                su0[0] = r0;
+                su1[0] = r1;
+                pend = true;
+            }
         }
         if constexpr (SM && !(ABL & 4)) {
             // cold: at most a handful of times per row block.  Every PV(i-1) MFMA has been issued: all of O and l is still
