@@ -150,6 +150,48 @@ def test_prefix_deferred_rescale_is_exact(dt, causal):
     assert (np.abs(lse.cpu().numpy() - wlse) <= 2e-3 + 1e-5 * np.abs(wlse)).all()
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("kind", ["all_far_below_zero", "ramp_per_block", "ramp_per_key", "plateau_just_under_the_bound", "late_spike_after_plateau"])
+def test_prefix_sum_tested_softmax_on_adversarial_scores(dt, kind):
+    """The 8-wave prefix unit has no maximum tree in its hot path: a block's probabilities are formed against the reference
+    as it stands and the lane's sum of them is tested against 2^8 (prefix_unit_w64.h, LAZY).  Score patterns chosen against
+    that test: every score far below zero (the reference must come down from its start value, nothing may underflow),
+    maxima that climb by less than the bound per block / per key (sums of moderate terms trip it, the reference follows),
+    a plateau of equal scores just under the bound and a spike behind it.  out AND lse against the float64 oracle."""
+    from hydragen_amd.flash import flash_attention
+
+    rng = np.random.default_rng({"all_far_below_zero": 1, "ramp_per_block": 2, "ramp_per_key": 3, "plateau_just_under_the_bound": 4,
+                                 "late_spike_after_plateau": 5}[kind])
+    b, sq, sk, hq, hkv, D = 1, 160, 1000, 4, 2, 128
+    unit = np.zeros(D, np.float32)
+    unit[:16] = 1.0                                   # q . k = 16 a b for q = a unit, k = b unit; log2-units = 16 a b * D^-0.5 * log2(e)
+    per = 16 * D ** -0.5 * 1.4426950408889634          # log2 units per unit of a * b
+    q = np.broadcast_to(unit, (b, sq, hq, D)).copy() + 0.01 * rng.standard_normal((b, sq, hq, D)).astype(np.float32)
+    j = np.arange(sk, dtype=np.float32)
+    if kind == "all_far_below_zero":
+        amp = np.full(sk, -60.0 / per) + rng.standard_normal(sk).astype(np.float32) * 0.5      # every score ~ -60 +- 1 (log2 units)
+    elif kind == "ramp_per_block":
+        amp = (6.0 * (j // 32)) / per                                                             # +6 per 32-key block: 2^6 x 16 keys > 2^8
+    elif kind == "ramp_per_key":
+        amp = (0.35 * j) / per                                                                    # +11 per block, smooth
+    elif kind == "plateau_just_under_the_bound":
+        amp = np.where(j < 40, 0.0, 7.5) / per                                                    # from key 40 on: 7.5 above the first reference
+    else:
+        amp = np.where(j < 40, 0.0, 7.5) / per
+        amp[977] = 30.0 / per
+    k = (amp[:, None] * unit[None, :])[None, :, None, :].repeat(hkv, 2).astype(np.float32)
+    k = k + 0.01 * rng.standard_normal(k.shape).astype(np.float32)
+    q, k = _round(q, dt), _round(k, dt)
+    v = _rand(rng, (b, sk, hkv, D), dt)
+    for causal in (False, True):
+        out, lse = flash_attention(dev(q, dt), dev(k, dt), dev(v, dt), causal=causal)
+        torch.cuda.synchronize()
+        want, wlse = O.flash_attention(q, k, v, causal=causal)
+        assert np.isfinite(out.float().cpu().numpy()).all() and np.isfinite(lse.cpu().numpy()).all()
+        assert_close(out.float().cpu().numpy(), want, dt, f"{kind} causal={causal}: out")
+        assert (np.abs(lse.cpu().numpy() - wlse) <= 2e-3 + 1e-5 * np.abs(wlse)).all(), kind
+
+
 @pytest.mark.parametrize("sk", [1, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 160, 255, 256, 257, 300, 511, 513])
 def test_prefix_lengths_around_block_boundaries(sk):
     """Keys are staged in 32-key blocks (two per 64-key half of a 128-key tile) by bounds-checked DMA: every
