@@ -305,7 +305,7 @@ constexpr int kElemGroupStartL[17] = {0, 4, 7, 10, 13, 16, 21, 23, 28, 30, 35, 3
 
 }  // namespace
 
-// ABL: development-only timing ablations (bit13 / bit14: see the DMA issue; bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
+// ABL: development-only timing ablations (bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
 // bit4 no barrier in the loop, bit5 no exp2, bit6 no element phase, bit7 no row sums / pack); only ABL = 0 ships.
 // QB: 32-row query blocks per wave.  2 for D <= 128 (64 rows per wave); 1 for D = 256, where one block's O accumulators
 // (8 x 16) and Q fragments (16 x 4) fill the same a[0:191] that two blocks fill at D = 128 (then always KG = 1: 128
@@ -737,20 +737,8 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
                     constexpr int i = j / EVERY;
                     if constexpr (i == 0) dma_m0(kdst[0] + kslot);
                     if constexpr (i == NLB) dma_m0(vdst[0] + vslot);
-                    // ABL bit 13: every in-loop DMA re-reads block 0 (cache-hot source); bit 14: past the end (zero fill, no memory traffic)
-                    // bit 15 (timing only, wrong results): row block rb starts its key stream rb / row_blocks of the way in
-                    unsigned ks_ = (ABL & 8192) ? 0u : (ABL & 16384) ? 0x7fff0000u : ksoff;
-                    unsigned vs_ = (ABL & 8192) ? 0u : (ABL & 16384) ? 0x7fff0000u : vsoff;
-                    if constexpr ((ABL & 32768) != 0) {
-                        const unsigned tk = (unsigned)(nkeys & ~127) * k_ts2, tv = (unsigned)(nkeys & ~127) * v_ts2;
-                        const unsigned rot = (unsigned)rb * (unsigned)((nkeys / a.row_blocks) & ~127);
-                        ks_ += rot * k_ts2; vs_ += rot * v_ts2;
-                        if (ks_ >= tk) ks_ -= tk;
-                        if (vs_ >= tv) vs_ -= tv;
-                        ks_ = __builtin_amdgcn_readfirstlane(ks_); vs_ = __builtin_amdgcn_readfirstlane(vs_);
-                    }
-                    if constexpr (i < NLB) dma16w<1024 * i, PERSIST>(krs, koffb[i], ks_);
-                    else dma16w<1024 * (i - NLB), PERSIST>(vrs, voffb[i - NLB], vs_);
+                    if constexpr (i < NLB) dma16w<1024 * i, PERSIST>(krs, koffb[i], ksoff);
+                    else dma16w<1024 * (i - NLB), PERSIST>(vrs, voffb[i - NLB], vsoff);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -859,8 +847,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         kso += ((R) & 1) ? k_lo : k_hi;                                                                      \
         vso += ((R) & 1) ? v_lo : v_hi;                                                                      \
         kwv += ((R) & 1) ? 32 : (KG == 2 ? 96 : 32);                                                         \
-        /* ABL bit 16 / 17 (timing only, racy): the barrier lets one / two more iterations' DMAs stay in flight */ \
-        dma_wait_w<((ABL & 131072) ? 6 : (ABL & 65536) ? 4 : 2) * NLB>();                                    \
+        dma_wait_w<2 * NLB>();                                                                               \
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();                                                       \
     }
         int i0 = -1;
