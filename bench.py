@@ -365,7 +365,8 @@ def main():
     suf_gbs = sum(suf_bytes) / (sum(suf_ms) * 1e-3) / 1e9
     pre_tflops = pre_flops * n_ev / (sum(pre_ms) * 1e-3) / 1e12
     suffix_roof = {
-        "kernel": "suffix_attn_kernel (suffix pass + fused LSE combine)",
+        "kernel": ("suffix_attn_gqa_kernel (matrix-core suffix pass for grouped-query heads + fused LSE combine)" if args.qheads // args.kvheads >= 4
+                   else "suffix_attn_kernel (suffix pass + fused LSE combine)"),
         "bound": "hbm", "achieved": suf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": suf_gbs / HBM_PEAK_GBS, "traffic": None,
         "avg_launch_us": sum(suf_ms) / n_ev * 1e3,
