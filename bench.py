@@ -528,6 +528,15 @@ def compact_line(res: dict) -> dict:
             d[path[1]] = d[path[1]][:97] + "..."
     if isinstance(line.get("events"), dict):
         line["events"].pop("steps", None)
+    acc = line.get("accuracy")
+    if isinstance(acc, dict):  # the top level IS the one-call form; keep the other forms' headline figure only
+        acc.pop("one_call_form", None)
+        for form in ("two_stream_form", "one_call_form_fp32_prefix_partial"):
+            if isinstance(acc.get(form), dict):
+                acc[form] = {k: acc[form][k] for k in ("relative_l2", "us_back_to_back") if k in acc[form]}
+    cfg = line.get("config")
+    if isinstance(cfg, dict) and isinstance(cfg.get("workload"), str) and "; suffix lengths of the timed steps:" in cfg["workload"]:
+        cfg["workload"] = cfg["workload"].split("; suffix lengths of the timed steps:")[0] + " (suffix lengths of the timed steps: config.suffix_lens)"
     # last resort, in order of dispensability
     for drop in (("paper_sweep", "rows"), ("reference_protocol", "by_suffix_len"), ("suffix_frac_by_suffix_len",), ("accuracy",), ("events",)):
         if len(json.dumps(line)) <= LINE_BUDGET:
