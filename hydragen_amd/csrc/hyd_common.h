@@ -67,6 +67,20 @@ struct Traits<BF16> {
     }
 };
 
+// A kernel's arguments span several 64-byte lines of the scalar cache, and hipcc fetches fields where it first needs them:
+// the fetches that miss wait for one another before the first global load is issued.  Touch the first four lines at once,
+// first thing in the kernel: one miss time instead of several (prefix pass: 1.1 k of 4.4 k prologue cycles).  The loads stay
+// in flight beside hipcc's own first argument fetches; the four registers (fixed: not ones hipcc's fetches are landing in)
+// stay claimed until the wait.
+__device__ __forceinline__ void warm_kernargs_256() {
+    const void* ka = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t0, t1, t2, t3;
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
+                 : "={s96}"(t0), "={s97}"(t1), "={s98}"(t2), "={s99}"(t3)
+                 : "s"(ka));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+{s96}"(t0), "+{s97}"(t1), "+{s98}"(t2), "+{s99}"(t3));
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 

@@ -11,18 +11,10 @@ namespace hyd {
 // to a part of the chip) -- persistent workgroups that walk the units with a stride of the grid.  Two instantiations on
 // purpose: wrapped in the unit loop, the body's loop-invariant scalars are hoisted and spilled to VGPR lanes, which
 // costs the one-unit launch 1-3 % (A/B against the round-2 library, tests/probes/ab_r2_prefix.py).
-// The kernel's 248 bytes of arguments span four 64-byte lines of the scalar cache, and hipcc fetches fields where it first
-// needs them: three of those fetches are misses that wait for one another before the first global load is issued (the
-// row decode needs fields of every line).  Touch every line at once, first thing: one miss time instead of three.
+// The kernel's 248 bytes of arguments are fetched in one scalar-cache miss (hyd_common.h, warm_kernargs_256).
 __device__ __forceinline__ void warm_kernargs() {
     static_assert(sizeof(PrefixArgs) <= 256, "four scalar-cache lines");
-    const void* ka = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned t0, t1, t2, t3;
-    // the loads stay in flight beside hipcc's own first argument fetches; the registers stay claimed until the wait below
-    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
-                 : "={s96}"(t0), "={s97}"(t1), "={s98}"(t2), "={s99}"(t3)  // (not registers hipcc's first fetches are landing in)
-                 : "s"(ka));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+{s96}"(t0), "+{s97}"(t1), "+{s98}"(t2), "+{s99}"(t3));
+    warm_kernargs_256();
 }
 
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false>

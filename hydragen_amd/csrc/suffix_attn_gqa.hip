@@ -39,6 +39,10 @@ namespace hyd {
 // NT: K/V loads carry the non-temporal hint (suffix_gqa_common.h): the unique phase, where every key is read once.
 template <typename T, int D, int WPU, bool NT>
 __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+    // every field a wave needs (and partials[0]) sits in the first 256 bytes of SuffixArgs: one scalar-cache miss at the start of
+    // a unit's dependent chain (C5 slice 7.17 -> 7.00 us at S = 16, 25.6 -> 24.9 at S = 128 in an A/B within one run; the dot-product
+    // kernel, whose 32768 waves all pay the four extra loads, lost 2-7 % at S <= 4 with it and does not have it)
+    warm_kernargs_256();
     using TR = Traits<T>;
     constexpr int RB = D * 2;        // bytes per K/V row
     constexpr int NCH = D / 32;      // 32-dim chunks of the QK^T contraction
