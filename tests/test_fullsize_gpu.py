@@ -78,6 +78,7 @@ CONFIGS = {
     "C3_b64_p16384_s256_gqa8": dict(B=64, P_levels=[(1, 16384)], S=256, Hq=32, Hkv=8, D=128),
     "C4_two_level_1024_32x64": dict(B=1024, P_levels=[(1, 1024), (32, 64)], S=32, Hq=32, Hkv=32, D=128),
     "C5_tp8_slice_b2048_p4096_8q1kv": dict(B=2048, P_levels=[(1, 4096)], S=256, Hq=8, Hkv=1, D=128),
+    "C5_whole_b2048_p4096_64q8kv": dict(B=2048, P_levels=[(1, 4096)], S=256, Hq=64, Hkv=8, D=128),  # configs[4] as north_star states it
 }
 
 
