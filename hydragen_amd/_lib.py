@@ -168,6 +168,13 @@ def load():
             f"{p} not found: build it with `python hydragen_amd/csrc/build.py` "
             "(or __graft_entry__.build()); there is no non-HIP fallback"
         )
+    if p == _LIB_PATH:
+        # the in-tree library: built by csrc/build.py, which stamps the prefix kernels' register-ownership check (csrc/regcheck.py)
+        missing = [s for s in ("prefix_attn_w64.regcheck", "prefix_attn_w64_f16.regcheck") if not (p.parent / s).exists()]
+        if missing:
+            raise HydragenLibraryError(
+                f"{p} was not built by hydragen_amd/csrc/build.py ({', '.join(missing)} missing): the prefix kernels' literal "
+                "registers are only safe with a compiler that passed csrc/regcheck.py -- rebuild with build.py")
     try:
         lib = C.CDLL(str(p))
     except OSError as e:  # pragma: no cover

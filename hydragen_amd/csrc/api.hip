@@ -42,28 +42,6 @@ struct PrefixPlan {
     int g, per, row_blocks, nsplit, split_len, grid, qpg, wg_rows;
 };
 
-// CUs of the current device (the in-launch merge of split-KV slices needs every workgroup of the launch resident at once);
-// kNumCU where no device can be asked (planner queries on a host without a GPU).
-int device_cus() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        return kNumCU;
-    }
-    return n;
-}
-
-// Split-KV slices are merged inside the prefix launch (prefix_unit_w64.h, merge_splits_in_launch) when its workgroups can
-// wait for one another: one workgroup per unit (no persistent launch) and one round of the chip.  Shapes + a device
-// attribute only: capture-safe.
-bool merges_in_launch(const hyd_prefix_params* p, const PrefixPlan& pl, int max_wgs) {
-    if (pl.nsplit <= 1 || pl.nsplit > 32 || dev_switch("HYD_NO_INLAUNCH_MERGE")) return false;
-    // the merge reads all slices through one 32-bit-offset buffer resource
-    if ((int64_t)pl.nsplit * (int64_t)align_up((size_t)p->B * p->nq * p->Hq * p->D * 4, 256) >= ((int64_t)1 << 31)) return false;
-    if (max_wgs > 0 && pl.grid > max_wgs) return false;
-    return pl.grid <= device_cus();
-}
-
 // softmax scale in base-2 exponent units: the caller's scale when it gives one, D^-0.5 otherwise
 float scale_log2e_of(float softmax_scale, int D) {
     return (softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)D)) * kLog2e;
@@ -161,13 +139,10 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMa
 // Split-KV slices are fp32 everywhere.  (16-bit slices on the fused decode path were measured: C3 80.5 -> 79.3 us,
 // C5 145.7 -> 140.9 us flushed, but every slice then carries its own rounding and the bf16 mean relative difference
 // of C3 / C5 / deep hierarchies rose from 0.8 % to 1.1-1.2 %, above the bound the parity tests state.)
-size_t arrival_bytes(const hyd_prefix_params* p, const PrefixPlan& pl) {  // one 64-bit word per (group, kv head, row block)
-    return align_up((size_t)p->sb * p->Hkv * pl.row_blocks * 8, 256);
-}
 size_t prefix_ws_bytes(const hyd_prefix_params* p, const PrefixPlan& pl, size_t esz = sizeof(float)) {
     if (pl.nsplit <= 1) return 0;
     const size_t rows = (size_t)p->B * p->nq * p->Hq;
-    return (size_t)pl.nsplit * (align_up(rows * p->D * esz, 256) + align_up(rows * sizeof(float), 256)) + arrival_bytes(p, pl);
+    return (size_t)pl.nsplit * (align_up(rows * p->D * esz, 256) + align_up(rows * sizeof(float), 256));
 }
 
 void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixArgs* a) {
@@ -213,12 +188,14 @@ void fill_prefix_args(const hyd_prefix_params* p, const PrefixPlan& pl, PrefixAr
     a->dbg = dev_switch("HYD_DBG");  // timing-ablation kernel variants; always 0 in product builds
 }
 
-// Run the prefix pass into p->out / p->lse (p->lse_layout; `out_f32`: an fp32 result -- only the decode entry asks for one).
-// With nsplit > 1 the kernel writes fp32 slices + [B, nq, Hq] LSEs into the workspace and merges them inside the launch
-// (merges_in_launch); where it cannot, `merge` runs the combine kernel behind it, and without `merge` the caller consumes the slices.
+// Run the prefix pass.  With nsplit > 1 the kernel writes fp32 slices + BQH LSEs into `ws`; if
+// `merge` they are then combined into p->out / p->lse, otherwise the caller consumes the slices.
 int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int grid, int max_wgs, hipStream_t s) {
     // max_wgs > 0: at most that many PERSISTENT workgroups walk the units (hyd_decode_params.shared_max_workgroups: the
     // rest of the chip stays free for work on another stream); 0 = one workgroup per unit
+#ifdef HYD_ABLATION_BUILD
+    if (const int np = dev_switch("HYD_PREFIX_PERSIST")) max_wgs = np;
+#endif
     if (max_wgs > 0 && grid > max_wgs) grid = max_wgs;
     return launch_prefix_w64(a, dtype, D, causal, grid, s);
 }
@@ -226,14 +203,11 @@ int launch_prefix_any(const PrefixArgs& a, int dtype, int D, bool causal, int gr
 int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hipStream_t s, int max_wgs = 0, bool out_f32 = false) {
     PrefixArgs a;
     fill_prefix_args(p, pl, &a);
-#ifdef HYD_ABLATION_BUILD
-    if (const int np = dev_switch("HYD_PREFIX_PERSIST")) max_wgs = np;
-#endif
     const size_t rows = (size_t)p->B * p->nq * p->Hq;
     if (pl.nsplit == 1) {
         a.out = p->out;
         a.lse = p->lse;
-        a.out_f32 = out_f32 ? 1 : 0;
+        a.out_f32 = out_f32 ? 1 : 0;  // only the decode entry asks for an fp32 partial (hyd_decode_params.f32_partials)
         a.lse_layout = p->lse_layout;
         int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, max_wgs, s);
         return rc ? fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc) : HYD_OK;
@@ -253,17 +227,9 @@ int run_prefix(const hyd_prefix_params* p, const PrefixPlan& pl, bool merge, hip
     a.lse_layout = HYD_LSE_BQH;
     a.out_split_stride = (int64_t)(o_bytes / esz);
     a.lse_split_stride = (int64_t)(l_bytes / sizeof(float));
-    const bool in_launch = merges_in_launch(p, pl, max_wgs);
-    if (in_launch) {
-        a.merge_mode = 1;
-        a.fin_out = p->out;
-        a.fin_lse = p->lse;
-        a.fin_f32 = out_f32 ? 1 : 0;
-        a.lse_layout = p->lse_layout;  // of fin_lse; the slices' LSEs stay [B, nq, Hq]
-    }
     int rc = launch_prefix_any(a, p->dtype, p->D, p->causal != 0, pl.grid, max_wgs, s);
     if (rc) return fail(HYD_ERR_LAUNCH, "prefix kernel launch failed: hip error %d", rc);
-    if (in_launch || !merge) return HYD_OK;
+    if (!merge) return HYD_OK;
     CombineArgs c;
     memset(&c, 0, sizeof(c));
     for (int i = 0; i < pl.nsplit; ++i) {
@@ -441,8 +407,7 @@ size_t unique_partial_bytes(const hyd_suffix_params& sp) {
 size_t level_ws_bytes(const hyd_prefix_params& pp, const PrefixPlan& pl, bool f32_partials) {
     const size_t rows = (size_t)pp.B * pp.nq * pp.Hq;
     const bool small = level_is_small(pp, pl);
-    // a split level: slices + arrival words, then the merged fp32 partial + LSE the in-launch merge leaves for the consumer
-    if (pl.nsplit > 1 && !small) return prefix_ws_bytes(&pp, pl) + align_up(rows * pp.D * 4, 256) + align_up(rows * 4, 256);
+    if (pl.nsplit > 1 && !small) return prefix_ws_bytes(&pp, pl);
     return align_up(rows * pp.D * ((f32_partials && !small) ? 4 : 2), 256) + align_up(rows * 4, 256);
 }
 
@@ -801,7 +766,7 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
         small[i] = level_is_small(pps[i], pls[i]);
         bytes[i] = level_ws_bytes(pps[i], pls[i], p->f32_partials != 0);
         need += bytes[i];
-        n_parts += (pls[i].nsplit == 1 || small[i] || merges_in_launch(&pps[i], pls[i], p->shared_max_workgroups)) ? 1 : pls[i].nsplit;
+        n_parts += (pls[i].nsplit == 1 || small[i]) ? 1 : pls[i].nsplit;
     }
     if (n_parts + (two_stream ? 1 : 0) > kMaxCombine) return fail(HYD_ERR_UNSUPPORTED, "%d partials (more than %d)", n_parts, kMaxCombine);
     if (decode_runs_as_one_launch(p, pps, pls, small)) {
@@ -836,28 +801,16 @@ int hyd_decode_attn_fused(const hyd_decode_params* p, void* stream) {
             parts[i].count = 1;
             parts[i].is_f32 = part_f32 ? 1 : 0;
         } else {
-            const size_t slices = prefix_ws_bytes(&pp, pl);
             pp.workspace = ws;
-            pp.workspace_bytes = slices;
-            if (merges_in_launch(&pp, pl, p->shared_max_workgroups)) {
-                // one merged fp32 partial behind the slices.  (fp32 whatever f32_partials says: the slices were fp32 when the
-                // consumer read them one by one, and a 16-bit merged partial would add the rounding the parity bounds of
-                // the split shapes -- C3, C5 -- were stated without.)
-                pp.out = ws + slices;
-                pp.lse = reinterpret_cast<float*>(ws + slices + align_up(rows * sp.D * 4, 256));
-                parts[i].out = pp.out;
-                parts[i].lse = pp.lse;
-                parts[i].count = 1;
-            } else {
-                parts[i].out = ws;
-                parts[i].lse = reinterpret_cast<const float*>(ws + (size_t)pl.nsplit * align_up(rows * sp.D * 4, 256));
-                parts[i].count = pl.nsplit;
-            }
+            pp.workspace_bytes = bytes[i];
+            parts[i].out = ws;
+            parts[i].lse = reinterpret_cast<const float*>(ws + (size_t)pl.nsplit * align_up(rows * sp.D * 4, 256));
+            parts[i].count = pl.nsplit;
             parts[i].is_f32 = 1;
         }
         if (do_shared) {
             if (small[i]) rc = run_level_small(pp, pl, const_cast<void*>(parts[i].out), const_cast<float*>(parts[i].lse), s);
-            else rc = run_prefix(&pp, pl, /*merge=*/false, s, p->shared_max_workgroups, part_f32 || pl.nsplit > 1);
+            else rc = run_prefix(&pp, pl, /*merge=*/false, s, p->shared_max_workgroups, part_f32);
             if (rc) return rc;
         }
         ws += bytes[i];

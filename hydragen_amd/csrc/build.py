@@ -42,9 +42,47 @@ def _compile(src: str, force: bool) -> Path:
     return obj
 
 
+# The prefix kernels keep O and Q in literal registers that only their asm statements name (prefix_unit_w64.h); whether
+# hipcc stays out of them is a property of the compiler release, so it is checked on the assembly of every (re)compile
+# (regcheck.py).  A failed check leaves no object, no stamp and no library behind: nothing loads, nothing computes wrongly.
+REGCHECKED = ["prefix_attn_w64.hip", "prefix_attn_w64_f16.hip"]
+
+
+def _stamp(src: str) -> Path:
+    return HERE / (Path(src).stem + ".regcheck")
+
+
+def _regcheck(src: str, force: bool) -> None:
+    from regcheck import check_prefix_asm  # (build.py runs as a script and as hydragen_amd.csrc.build: plain import by path)
+
+    stamp = _stamp(src)
+    if not (force or _stale(stamp, [src] + HEADERS + ["build.py", "regcheck.py"])):
+        return
+    stamp.unlink(missing_ok=True)
+    cmd = [HIPCC, *[f for f in FLAGS if f not in ("-fPIC", "-Werror")], "-S", "--cuda-device-only", str(HERE / src), "-o", "-"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
+    check_prefix_asm(r.stdout, src)
+    ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()
+    stamp.write_text("registers checked: " + (ver[0] if ver else "hipcc") + "\n")
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
+    if str(HERE) not in sys.path:
+        sys.path.insert(0, str(HERE))
     with ThreadPoolExecutor(max_workers=6) as ex:
+        checks = [ex.submit(_regcheck, s, force) for s in REGCHECKED]
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+        try:
+            for c in checks:
+                c.result()
+        except Exception:
+            for s in REGCHECKED:  # nothing built from these sources may survive
+                (HERE / (Path(s).stem + ".o")).unlink(missing_ok=True)
+                _stamp(s).unlink(missing_ok=True)
+            LIB.unlink(missing_ok=True)
+            raise
     if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
         r = subprocess.run(cmd, capture_output=True, text=True)

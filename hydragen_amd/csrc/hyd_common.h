@@ -76,8 +76,9 @@ __device__ __forceinline__ void warm_kernargs_256() {
     const void* ka = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned t0, t1, t2, t3;
     asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
-                 : "={s96}"(t0), "={s97}"(t1), "={s98}"(t2), "={s99}"(t3)
-                 : "s"(ka));
+                 : "=&{s96}"(t0), "=&{s97}"(t1), "=&{s98}"(t2), "=&{s99}"(t3)  // early-clobber: the base may not share s[96:99]
+                 : "s"(ka)
+                 : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" : "+{s96}"(t0), "+{s97}"(t1), "+{s98}"(t2), "+{s99}"(t3));
 }
 

@@ -28,11 +28,6 @@ struct PrefixArgs {
     const void* v;
     void* out;   // dtype [..] or fp32 when out_f32; split sp writes at out + sp*out_split_stride
     float* lse;  // may be null
-    // in-launch merge of the split-KV slices (merge_mode != 0, prefix_unit_w64.h: merge_splits_in_launch): `out` / `lse` are
-    // then the fp32 slices + their [B, nq, Hq] LSEs in the workspace, fin_out / fin_lse the ONE merged result; the arrival
-    // words of the row blocks sit right behind the LSE slices (lse + nsplit * lse_split_stride, 8 bytes per row block)
-    void* fin_out;   // 16-bit dtype, or fp32 when fin_f32
-    float* fin_lse;  // may be null; layout lse_layout
     const int32_t* cu_k;
     const int32_t* cu_q;
     int64_t k_gs, k_ts, k_hs, v_gs, v_ts, v_hs;
@@ -46,7 +41,6 @@ struct PrefixArgs {
     int32_t wg_rows;  // query rows per workgroup: 128, or 256 (pipelined kernel, D = 128, large row counts)
     int32_t waves;    // waves per workgroup: 4 (one per SIMD, 64-row waves) or 8 (two per SIMD, 32-row waves; D = 128)
     int32_t lse_layout, out_f32;
-    int32_t merge_mode, fin_f32;
     float scale_log2e;
     FastDiv div_row_blocks, div_nsplit, div_hkv, div_g;  // the unit / row decode divides by these four
     int32_t dbg;  // 0 in product builds; HYD_ABLATION_BUILD reads HYD_DBG to pick a timing-ablation variant of a prefix kernel

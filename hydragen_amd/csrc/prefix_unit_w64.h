@@ -305,133 +305,6 @@ constexpr int kElemGroupStartL[17] = {0, 4, 7, 10, 13, 16, 21, 23, 28, 30, 35, 3
 
 }  // namespace
 
-// In-launch merge of a row block's split-KV slices (replaces _splitK_reduce, /root/reference/hydragen/flash.py:76-160, and
-// the separate combine launch / the slice reads of the suffix epilogue that stood in for it).  Every workgroup of the launch is
-// resident at once (the host only sets merge_mode when the grid fits the chip's CUs in one round), so the nsplit workgroups
-// of a row block can wait for one another: each writes its normalised fp32 slice + LSEs, takes a ticket on the row
-// block's arrival word and, once all nsplit tickets are drawn, reduces rows [sp * rps, (sp + 1) * rps) of the block over
-// ALL slices -- every workgroup reads 1 / nsplit of the rows, in parallel -- into the ONE partial (+ LSE) the consumer reads.
-// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md guideline 16, form R1): the slices
-// and their LSEs are stored WRITE-THROUGH (sc1: an XCD's L2 keeps no dirty copy, so no L2 write-back is needed -- an
-// agent-scope release fence per workgroup, measured first, costs 100 us at C3: 256 write-backs of freshly dirtied L2s);
-// every storing wave drains its stores, the barrier orders them before thread 0's ticket; the reader polls one word
-// relaxed and reads the slices with sc1 loads (served by L2 / fabric, never by a stale line of the CU's vector cache).
-// Nothing depends on which XCD a workgroup runs on; keeping a row block's splits on one XCD is a speed choice only.
-// The arrival word needs no initialisation by the host (the library never clears the caller's workspace, and a
-// hipMemsetAsync node in front of every prefix launch would cost a kernel boundary): it is a 64-bit word
-// {tag:52, departures:6, arrivals:6}; a word whose tag does not match counts as zero -- the compare-and-swap of the first
-// arrival installs the tag, whatever the memory held -- and the last workgroup to leave puts {tag, 0, 0} back for the next
-// launch on this workspace.  (52 tag bits: a stray word of stale data matches with probability 2^-52.)
-constexpr unsigned long long kArriveTag = 0x7fb1a5edc0de5000ull;
-constexpr unsigned long long kArriveTagMask = ~0xfffull;
-template <typename T, int D, int NT>
-__device__ __forceinline__ void merge_splits_in_launch(const PrefixArgs& a, int gi, int hk, int rb, int sp, int q_tok0, int Mrows, int rwg) {
-    using TR = Traits<T>;
-    constexpr int kSpinLimit = 1 << 20;  // polls (~1 us each); never reached: every workgroup of the launch is resident
-    const int tid = threadIdx.x;
-    const unsigned ns = (unsigned)a.nsplit;
-    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.lse + (int64_t)a.nsplit * a.lse_split_stride) +
-                              ((int64_t)gi * a.Hkv + hk) * a.row_blocks + rb;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have left the CU
-    __syncthreads();
-    unsigned long long dep = 0ull;  // thread 0: the word before its departure (looked at after the reduction: not on the critical path)
-    bool counted = false;
-    if (tid == 0) {
-        // Ticket.  Steady state (the word is {tag, 0, 0} + earlier arrivals): ONE fetch-add, no retry under contention.  A word
-        // that does not carry the tag (first launch on this workspace) is repaired by compare-and-swap to {tag, 0, 1}; a
-        // workgroup whose fetch-add fell on the garbage before the repair finds the tag afterwards and draws again.
-        unsigned long long old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned arrived = ((unsigned)old & 0x3fu) + 1u;
-        if ((old & kArriveTagMask) != kArriveTag) {
-            unsigned long long cur = old + 1ull;
-            for (;;) {
-                if ((cur & kArriveTagMask) == kArriveTag) {  // repaired by another workgroup: my first ticket is gone with the garbage
-                    cur = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((cur & kArriveTagMask) == kArriveTag) { arrived = ((unsigned)cur & 0x3fu) + 1u; break; }
-                    cur += 1ull;
-                    continue;
-                }
-                if (__hip_atomic_compare_exchange_strong(ctr, &cur, kArriveTag + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    arrived = 1u;
-                    break;
-                }
-            }
-        }
-        int polls = 0;
-        while (arrived < ns) {
-            if (++polls > kSpinLimit) break;
-            __builtin_amdgcn_s_sleep(1);
-            arrived = (unsigned)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x3fu;
-        }
-        counted = arrived >= ns;
-        if (counted) dep = __hip_atomic_fetch_add(ctr, 1ull << 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // timed out: leave no half-counted word behind
-    }
-    __syncthreads();
-
-    constexpr int CPR = D / 4;     // 16-byte fp32 chunks per row
-    constexpr int RPP = NT / CPR;  // rows per pass of the workgroup
-    static_assert(NT % CPR == 0, "whole rows per pass");
-    const int rps = (rwg + a.nsplit - 1) / a.nsplit;
-    const int r_end = min(min(rwg, (sp + 1) * rps), Mrows - rb * rwg);
-    const int c = tid % CPR;
-    // all slices through one buffer resource (the host keeps nsplit slices below 2 GiB), read with sc1
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)(a.nsplit * a.out_split_stride * 4), 0x00020000);
-    const unsigned sstride = (unsigned)(a.out_split_stride * 4);
-    for (int r = sp * rps + tid / CPR; r < r_end; r += RPP) {
-        const unsigned rg = (unsigned)(rb * rwg + r);
-        const unsigned t = __umulhi(rg, a.div_g.mul);
-        const int tok = (int)((t + ((rg - t) >> (a.div_g.sh & 0xffu))) >> (a.div_g.sh >> 8));
-        const int hqv = hk * a.g + ((int)rg - tok * a.g);
-        const int64_t ridx = (int64_t)(q_tok0 + tok) * a.Hq + hqv;
-        const unsigned so = (unsigned)((ridx * D + 4 * c) * 4);
-        const float* sl = a.lse + ridx;
-        float m = -INFINITY, den = 0.f;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < a.nsplit; s0 += 8) {  // up to 8 slices per round trip (wave-uniform guards)
-            float lv[8];
-            f32x4 x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                lv[j] = -INFINITY;
-                x[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (s0 + j < a.nsplit) {
-                    lv[j] = __hip_atomic_load(sl + (int64_t)(s0 + j) * a.lse_split_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, so, (unsigned)(s0 + j) * sstride, /*sc1*/ 16));
-                }
-            }
-            float mn = m;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mn = fmaxf(mn, lv[j]);
-            const float ms = (mn == -INFINITY) ? 0.f : mn;
-            const float al = fast_exp2((m - ms) * kLog2e);
-            den *= al;
-            acc *= al;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float w = fast_exp2((lv[j] - ms) * kLog2e);
-                den += w;
-                acc += x[j] * w;
-            }
-            m = mn;
-        }
-        const float inv = den > 0.f ? 1.0f / den : 0.f;
-        acc *= inv;
-        if (a.fin_f32) {
-            *reinterpret_cast<f32x4*>(static_cast<float*>(a.fin_out) + ridx * D + 4 * c) = acc;
-        } else {
-            const u32x2 pk = {TR::pack2(acc[0], acc[1]), TR::pack2(acc[2], acc[3])};
-            *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.fin_out) + ridx * D + 4 * c) = pk;
-        }
-        if (a.fin_lse && c == 0) {
-            const int64_t idx = a.lse_layout == HYD_LSE_BQH ? ridx : ((int64_t)gi * a.Hq + hqv) * a.lse_q_stride + tok;
-            a.fin_lse[idx] = den > 0.f ? m + __logf(den) : -INFINITY;
-        }
-    }
-    // the last workgroup to leave hands the next launch a clean word
-    if (tid == 0 && counted && (((unsigned)dep >> 6) & 0x3fu) == ns - 1u) __hip_atomic_store(ctr, kArriveTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ABL: development-only timing ablations (bit0 no in-loop DMA, bit2 no softmax VALU, bit3 no LDS fragment reads,
 // bit4 no barrier in the loop, bit5 no exp2, bit6 no element phase, bit7 no row sums / pack); only ABL = 0 ships.
 // QB: 32-row query blocks per wave.  2 for D <= 128 (64 rows per wave); 1 for D = 256, where one block's O accumulators
@@ -465,12 +338,19 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     constexpr int RING_BYTES = (KG == 2 ? 512 : 256) * RB;
     float* mlbuf = reinterpret_cast<float*>(smem + RING_BYTES);  // [NW waves][QB][2][64] (KG = 2 merge)
 
-    unsigned tst[6] = {0, 0, 0, 0, 0, 0};  // ABL bit 11: cycle stamps of workgroup 0 (development builds only)
+    // ABL bit 11 (development builds only): time stamps of EVERY workgroup's wave 0 -- s_memtime (shader-clock cycles) at six
+    // points, s_memrealtime (the constant 100 MHz counter) at the first and the last: where a workgroup's time goes, when it
+    // started relative to the others, and the clock it ran at (cycles / real time), tools/prefix_timeline.py.
+    unsigned tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stampk = [&](int k) __attribute__((always_inline)) {
         if constexpr ((ABL & 2048) != 0) {
             uint64_t t;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
             tst[k] = (unsigned)t;
+            if (k == 0 || k == 5) {
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                tst[k == 0 ? 6 : 7] = (unsigned)t;
+            }
         }
     };
     stampk(0);
@@ -492,19 +372,10 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         return (t + ((n - t) >> (f.sh & 0xffu))) >> (f.sh >> 8);
     };
     const int lin = xcd_remap(vblock, vgrid);
-    int rb, sp, t2_;
-    if (!PERSIST && a.merge_mode) {
-        // in-launch merge: the splits of a row block are neighbours (one XCD, one L2: their slices are merged out of it)
-        const int t_ = (int)fdiv((unsigned)lin, a.div_nsplit);
-        sp = lin - t_ * a.nsplit;
-        t2_ = (int)fdiv((unsigned)t_, a.div_row_blocks);
-        rb = t_ - t2_ * a.row_blocks;
-    } else {
-        const int t_ = (int)fdiv((unsigned)lin, a.div_row_blocks);
-        rb = lin - t_ * a.row_blocks;
-        t2_ = (int)fdiv((unsigned)t_, a.div_nsplit);
-        sp = t_ - t2_ * a.nsplit;
-    }
+    int t_ = (int)fdiv((unsigned)lin, a.div_row_blocks);
+    const int rb = lin - t_ * a.row_blocks;
+    const int t2_ = (int)fdiv((unsigned)t_, a.div_nsplit);
+    const int sp = t_ - t2_ * a.nsplit;
     const int gi = (int)fdiv((unsigned)t2_, a.div_hkv);
     const int hk = t2_ - gi * a.Hkv;
 
@@ -1091,19 +962,9 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
             }
             if (a.out_f32) {
                 if (rvalid_q) {
-                    if (!PERSIST && a.merge_mode) {
-                        // slices of the in-launch merge: write-through (sc1) stores, see merge_splits_in_launch
-                        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
-                            static_cast<float*>(a.out) + (int64_t)sp * a.out_split_stride, 0, (int)(unsigned)(a.out_split_stride * 4), 0x00020000);
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[q4]), ors,
-                                                                   (unsigned)((row_off_q + 32 * db + 8 * q4 + 4 * hi) * 4), 0, /*sc1*/ 16);
-                    } else {
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + obase + 32 * db + 8 * q4 + 4 * hi) = x[q4];
-                    }
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + obase + 32 * db + 8 * q4 + 4 * hi) = x[q4];
                 }
             } else {
 #pragma unroll
@@ -1126,24 +987,24 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         if (a.lse && kg == 0 && hi == 0 && rvalid_q) {
             const float lse = lf > 0.f ? mf * kLn2 + __logf(lf) : -INFINITY;
             int64_t idx;
-            if (a.lse_layout == HYD_LSE_BQH || a.merge_mode)  // (slices of the in-launch merge: always [B, nq, Hq])
+            if (a.lse_layout == HYD_LSE_BQH)
                 idx = (int64_t)(q_tok0 + rtok_q) * a.Hq + hq_q;
             else
                 idx = ((int64_t)gi * a.Hq + hq_q) * a.lse_q_stride + rtok_q;
-            if (!PERSIST && a.merge_mode) __hip_atomic_store(a.lse + (int64_t)sp * a.lse_split_stride + idx, lse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else a.lse[(int64_t)sp * a.lse_split_stride + idx] = lse;
+            a.lse[(int64_t)sp * a.lse_split_stride + idx] = lse;
         }
     });
-    if constexpr (!PERSIST) {
-        if (a.merge_mode) merge_splits_in_launch<T, D, 64 * NW>(a, gi, hk, rb, sp, q_tok0, Mrows, RWG);
-    }
     if constexpr ((ABL & 2048) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stampk(5);
-        if (blockIdx.x == 0 && lane < 6) {
+        if (wave == 0 && lane < 12) {  // record of this workgroup: 16 words behind the LSEs
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hwid));
             unsigned tv = tst[0];
-            for (int q_ = 1; q_ < 6; ++q_) tv = lane == q_ ? tst[q_] : tv;
-            reinterpret_cast<unsigned*>(a.lse)[(size_t)a.B * a.nq * a.Hq + wave * 8 + lane] = tv;
+            for (int q_ = 1; q_ < 8; ++q_) tv = lane == q_ ? tst[q_] : tv;
+            tv = lane == 8 ? xcc : lane == 9 ? hwid : lane == 10 ? (unsigned)blockIdx.x : lane == 11 ? (unsigned)lin : tv;
+            const size_t tail = a.nsplit > 1 ? (size_t)a.nsplit * (size_t)a.lse_split_stride : (size_t)a.B * a.nq * a.Hq;  // behind the LSEs
+            reinterpret_cast<unsigned*>(a.lse)[tail + (size_t)blockIdx.x * 16 + lane] = tv;
         }
     }
 }
