@@ -99,6 +99,7 @@ def parse():
     ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--model-new-tokens", type=int, default=128)
+    ap.add_argument("--detail-out", default="", help="where the full (uncompacted) result goes; default gpurun_out/bench_detail.json (scratch)")
     ap.add_argument("--no-xgmi", action="store_true", help="N > 1: skip the direct xGMI all-reduce (hyd_allreduce_sum) leg")
     ap.add_argument("--no-graph-collective", action="store_true",
                     help="N > 1: skip the HIP-graph capture of (attention + all-reduce), llama.py:849-854")
@@ -245,9 +246,10 @@ def main():
     dev_index = 0 if os.environ.get("HYD_BENCH_ONE_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    pre = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        pre = preflight(args, rank, world, backend, dev)  # initialises the process group (stage rccl_init); exits 3 on a hard failure
 
     B, P, S, D = args.batch, args.prefix, args.max_suffix, args.dim
     assert args.qheads % world == 0 and args.kvheads % world == 0, "heads must divide the TP degree (tp.py:43-46)"
@@ -256,8 +258,8 @@ def main():
     dt = torch.bfloat16
     torch.manual_seed(1234 + rank)
     q = torch.randn(B, 1, Hq, D, device=dev, dtype=dt)
-    k = torch.randn(B, S, Hkv, D, device=dev, dtype=dt)
-    v = torch.randn(B, S, Hkv, D, device=dev, dtype=dt)
+    kv = torch.randn(2, B, S, Hkv, D, device=dev, dtype=dt)  # one arena, K | V, as PerLayerKVCache allocates a layer's unique caches
+    k, v = kv[0], kv[1]
     sk = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
     sv = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
     sched = suffix_schedule(args.steps, S)
@@ -416,6 +418,9 @@ def main():
             "suffix_len_mean": sum(sched) / len(sched), "qheads": args.qheads, "kvheads": args.kvheads, "head_dim": D,
             "parallelism": f"tp{world} (heads sharded, all-reduce [B,1,{hidden}] bf16 per step)" if world > 1 else "single GPU",
         },
+        # `value` is an attention-LAYER rate; the whole-model decode rate is the next key (filled by the model leg, N = 1, c2)
+        "value_is": "batch / one layer's attention time (attn_us_per_step); NOT decode throughput: that is decode_tokens_per_sec",
+        "decode_tokens_per_sec": None,
         "attn_us_per_step": elapsed / args.steps * 1e6,
         "prefix_us": sum(pre_ms) / n_ev * 1e3,
         "suffix_us_mean": sum(suf_ms) / n_ev * 1e3,
@@ -437,6 +442,7 @@ def main():
         "roofline_other": prefix_roof if dominant_is_suffix else suffix_roof,
     }
     if world > 1:
+        res["preflight"] = pre
         ar_ms = [ev[2].elapsed_time(ev[3]) for ev in events]
         res["allreduce_us"] = sum(ar_ms) / n_ev * 1e3
         res["allreduce_bytes"] = ar_buf.numel() * 2
@@ -472,6 +478,9 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:  # whole-job head counts, so that it compares with `value` at any N
         res["cpu_baseline"] = cpu_baseline(B, P, args.qheads, args.kvheads, D, args.cpu_seconds)
     if rank == 0:
+        if args.detail_out:
+            global DETAIL_FILE
+            DETAIL_FILE = Path(args.detail_out).resolve()
         print(json.dumps(compact_line(res)))
         sys.stdout.flush()
     if world > 1:
@@ -479,7 +488,34 @@ def main():
         dist.destroy_process_group()
 
 
-DETAIL_FILE = REPO / "profiles" / "bench_detail_latest.json"
+def _setup_caches_one_aliased_unique_buffer(model, max_unique_batch_size, max_unique_seq_length, max_shared_batch_sizes, max_shared_seq_lengths):
+    """What `setup_caches` does (hydragen_amd/llama.py; /root/reference/hydragen/llama.py:921-955), except that every layer's
+    unique K/V cache is ONE pair of buffers.  A timing stand-in for the no-sharing baseline at the headline batch
+    (scripts/synth.py:112,151 replicates the prefix into every sequence's cache: 36 GB per LAYER at batch 1024 / prefix 2048):
+    the generated tokens are meaningless -- the layers overwrite each other's keys -- the time per step is not, every layer
+    still appends to and streams the whole buffer from HBM.  Lives here, not on the model's API, which mirrors the reference's."""
+    from hydragen_amd.llama import PerLayerKVCache
+
+    model.maybe_invalidate()
+    max_unique_seq_length = (max_unique_seq_length + 15) // 16 * 16
+    first = None
+    for layer in model.model.layers:
+        alias = first is not None
+        cache = PerLayerKVCache(
+            max_unique_batch_size=1 if alias else max_unique_batch_size, max_unique_seq_length=16 if alias else max_unique_seq_length,
+            max_shared_batch_sizes=max_shared_batch_sizes, max_shared_seq_lengths=max_shared_seq_lengths,
+            n_kv_heads=model.config.num_key_value_heads, head_dim=model.config.hidden_size // model.get_num_heads(),
+            device=model.lm_head.weight.device, dtype=model.lm_head.weight.dtype)
+        if alias:
+            cache.per_completion_k_cache = first.per_completion_k_cache
+            cache.per_completion_v_cache = first.per_completion_v_cache
+        else:
+            first = cache
+        layer.self_attn.kv_cache = cache
+    model.kv_cache_allocated = True
+
+
+DETAIL_FILE = REPO / "gpurun_out" / "bench_detail.json"  # scratch (untracked); --detail-out moves it; tools/profile_round.sh copies the round's into profiles/
 LINE_BUDGET = 7600  # bytes: the driver's record keeps the last 8 KB of the line
 
 
@@ -498,11 +534,11 @@ def _round_floats(o):
 def compact_line(res: dict) -> dict:
     """The ONE line the driver records must fit its 8 KB tail.  The full result (per-point std / rstd / n of the reference
     protocol, the paper sweep's rows as objects, the prose that says how each figure was taken) goes to
-    profiles/bench_detail_latest.json; the line keeps every figure's MEAN, five significant digits, and short notes."""
+    the detail file (DETAIL_FILE / --detail-out); the line keeps every figure's MEAN, five significant digits, and short notes."""
     try:
-        DETAIL_FILE.parent.mkdir(exist_ok=True)
+        DETAIL_FILE.parent.mkdir(parents=True, exist_ok=True)
         DETAIL_FILE.write_text(json.dumps(res, indent=1))
-        detail = str(DETAIL_FILE.relative_to(REPO))
+        detail = str(DETAIL_FILE.relative_to(REPO)) if DETAIL_FILE.is_relative_to(REPO) else str(DETAIL_FILE)
     except OSError as ex:  # a read-only tree must not cost the line
         detail = f"not written ({type(ex).__name__})"
     keep = ("value", "ms_per_step", "attn_us_per_step")  # the contract's own figures stay as measured
@@ -628,6 +664,154 @@ def _attach_traffic(suffix_roof, prefix_roof, args, world):
             roof["traffic_over_algorithmic"] = b / t[f"{key}_algorithmic_bytes_per_launch"]
 
 
+PREFLIGHT_STAGE_SECONDS = 60.0
+
+
+def preflight(args, rank, world, backend, dev):
+    """N > 1, before anything is timed: the pieces a first run on a multi-GPU node can fail in, one by one, each under its own
+    60 s watchdog, so that a failure NAMES its stage instead of hanging the job or surfacing as a wrong number later
+    (the bootstrap and collectives of /root/reference/hydragen/utils.py:118-133, tp.py:108-112, the in-graph collective of
+    llama.py:849-854).  Rank 0 prints one `[preflight] {json}` line per stage.  Stages:
+      devices          visible devices >= N (one-device self-test mode excepted)
+      rccl_init        init_process_group with N ranks + a 1 KiB all-reduce checked against the expected sum
+      peer_access      hipDeviceCanAccessPeer for every ordered pair of the N devices
+      xgmi_allreduce   one hyd_allreduce_sum (XgmiAllReduce) of 1 MiB checked against the process group's result  [--no-xgmi skips]
+      graph_collective a captured all-reduce replayed twice, result checked                                       [--no-graph-collective skips]
+    A failed or hung devices / rccl_init / peer_access stage ends the job: error line naming the stage, exit code 3.  A FAILED
+    xgmi_allreduce or graph_collective stage only switches that optional leg off -- the RCCL headline still runs; a HUNG one
+    cannot be recovered from (the process group is stuck) and exits 3, the line says which flag skips the stage.
+    Returns {stage: {...}} for the result line; may set args.no_xgmi / args.no_graph_collective."""
+    report, one_device = {}, bool(os.environ.get("HYD_BENCH_ONE_DEVICE"))
+
+    def say(stage, rec):
+        report[stage] = rec
+        if rank == 0:
+            print("[preflight] " + json.dumps({"stage": stage, **rec}))
+            sys.stdout.flush()
+
+    def die(stage, why, hint=""):
+        line = {"metric": "decode_attention_tokens_per_sec", "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "error": f"preflight stage '{stage}' failed on rank {rank}: {why}" + (f" ({hint})" if hint else ""),
+                "preflight_stage": stage, "rank": rank, "preflight": report}
+        print(json.dumps(line))
+        sys.stdout.flush()
+        os._exit(3)
+
+    def staged(stage, fn, optional_flag=None):
+        """Run one stage under the watchdog.  Hard stages die on any failure; optional ones only on a hang."""
+        hint = f"--{optional_flag.replace('_', '-')} skips this stage" if optional_flag else ""
+        timer = threading.Timer(PREFLIGHT_STAGE_SECONDS, lambda: die(stage, f"no answer within {PREFLIGHT_STAGE_SECONDS:.0f} s", hint))
+        timer.daemon = True
+        timer.start()
+        t0 = time.perf_counter()
+        try:
+            if os.environ.get("HYD_BENCH_FAIL_STAGE") == stage:  # self-test knob (tests/test_bench.py), like HYD_BENCH_BACKEND
+                raise RuntimeError("failure injected by HYD_BENCH_FAIL_STAGE")
+            rec = fn() or {}
+            say(stage, {"ok": True, "seconds": round(time.perf_counter() - t0, 3), **rec})
+            return True
+        except Exception as ex:  # noqa: BLE001 -- every failure must name its stage
+            why = f"{type(ex).__name__}: {ex}"
+            if optional_flag is None:
+                timer.cancel()
+                die(stage, why)
+            say(stage, {"ok": False, "seconds": round(time.perf_counter() - t0, 3), "error": why[:300], "consequence": f"leg switched off ({hint})"})
+            setattr(args, optional_flag, True)
+            return False
+        finally:
+            timer.cancel()
+
+    def reduce_any(t):
+        """all-reduce(sum) through the process group: RCCL on the device, or (gloo self-test) a host copy."""
+        if backend == "nccl":
+            dist.all_reduce(t)
+            return t
+        h = t.float().cpu()
+        dist.all_reduce(h)
+        return h.to(device=t.device, dtype=t.dtype)
+
+    def st_devices():
+        n = torch.cuda.device_count()
+        if not one_device and n < world:
+            raise RuntimeError(f"{n} visible devices for {world} ranks")
+        return {"visible_devices": n, "one_device_self_test": one_device}
+
+    def st_init():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        x = torch.full((256,), float(rank + 1), device=dev, dtype=torch.float32)  # 1 KiB
+        got = reduce_any(x)
+        torch.cuda.synchronize()
+        want = world * (world + 1) / 2
+        if not bool((got == want).all()):
+            raise RuntimeError(f"1 KiB all-reduce returned {float(got[0])}, expected {want}")
+        return {"backend": backend, "ranks": dist.get_world_size(), "all_reduce_1KiB": "sum checked"}
+
+    def st_peer():
+        n = world if not one_device else 1
+        m = [[int(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
+        if not all(all(r) for r in m):
+            raise RuntimeError(f"hipDeviceCanAccessPeer matrix has holes: {m}")
+        return {"can_access_peer": m}
+
+    def st_xgmi():
+        from hydragen_amd.xgmi_allreduce import XgmiAllReduce
+
+        comm = XgmiAllReduce(max_bytes=1 << 20, timeout_log2_polls=24)  # ~5 s per wait: well inside the stage's watchdog
+        try:
+            gen = torch.Generator(device=dev).manual_seed(77 + rank)
+            x = torch.randn(1 << 19, device=dev, dtype=torch.bfloat16, generator=gen)  # 1 MiB
+            want = reduce_any(x.clone())
+            got = comm.all_reduce_(x.clone())
+            torch.cuda.synchronize()
+            err = float((got.float() - want.float()).abs().max())
+            st = comm.status()
+            # same addends, another order of summation in bf16: a few units in the last place of O(sqrt(world)) values
+            if not (err <= 0.0625 * max(1.0, world ** 0.5)) or not torch.isfinite(got.float()).all():
+                raise RuntimeError(f"1 MiB hyd_allreduce_sum differs from the process group's result by {err} (status {st})")
+            dist.barrier()
+            return {"bytes": 1 << 20, "max_abs_diff_vs_group": err, "uncached_block": bool(comm.uncached), "status": st}
+        finally:
+            comm.close()
+
+    def st_graph():
+        if backend != "nccl":
+            return {"skipped": "the in-graph collective is RCCL's (llama.py:849-854); this run uses " + backend}
+        x = torch.full((1 << 18,), float(rank + 1), device=dev, dtype=torch.float32)  # 1 MiB
+        y = torch.empty_like(x)
+
+        def fn():
+            y.copy_(x)
+            dist.all_reduce(y)
+
+        g = _capture(fn)
+        want = world * (world + 1) / 2
+        for i in range(2):
+            y.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            if not bool((y == want).all()):
+                raise RuntimeError(f"replay {i} of a captured all-reduce returned {float(y[0])}, expected {want}")
+        return {"replays": 2, "bytes": 1 << 20}
+
+    def agree(flag):
+        """An optional leg runs on every rank or on none: one rank's failed stage switches it off everywhere."""
+        off = reduce_any(torch.tensor([1.0 if getattr(args, flag) else 0.0], device=dev))
+        torch.cuda.synchronize()
+        if float(off[0]) > 0:
+            setattr(args, flag, True)
+
+    staged("devices", st_devices)
+    staged("rccl_init", st_init)
+    staged("peer_access", st_peer)
+    if not args.no_xgmi:
+        staged("xgmi_allreduce", st_xgmi, "no_xgmi")
+    if not args.no_graph_collective:
+        staged("graph_collective", st_graph, "no_graph_collective")
+    staged("agreement", lambda: (agree("no_xgmi"), agree("no_graph_collective"),
+                                 {"xgmi_leg": not args.no_xgmi, "graph_collective_leg": not args.no_graph_collective})[2])
+    return report
+
+
 def _region_watchdog(args, rank, world):
     """Timer that ends this rank with an error line when the warm-up / timed region of an N > 1 run does not finish in
     --region-timeout seconds.  Every rank prints the line (a hung rank 0 cannot speak for the others); the exit code is
@@ -712,8 +896,13 @@ def xgmi_allreduce_leg(ar_buf):
 
     comm = XgmiAllReduce(max_bytes=ar_buf.numel() * ar_buf.element_size())
     x = torch.randn_like(ar_buf)
-    want = x.clone()
-    dist.all_reduce(want)
+    if dist.get_backend() == "nccl":
+        want = x.clone()
+        dist.all_reduce(want)
+    else:  # gloo self-test: reduce a host copy
+        h = x.float().cpu()
+        dist.all_reduce(h)
+        want = h.to(x.device)
     got = comm.all_reduce_(x.clone())
     torch.cuda.synchronize()
     err = float((got.float() - want.float()).abs().max())
@@ -954,10 +1143,9 @@ def model_decode(B, P, new_tokens):
 
     def noshared_full_batch(new=6):
         """hydragen_noshared AT THE HEADLINE BATCH: one private [B, P + new] K/V buffer (36 GB at B = 1024, P = 2048) aliased
-        by all layers (setup_caches(timing_only_alias_unique_cache=True)): every layer streams it from HBM in every step,
+        by all layers (_setup_caches_one_aliased_unique_buffer): every layer streams it from HBM in every step,
         which is what the mode costs; 32 private copies (1.2 TB) would not fit."""
-        model.setup_caches(max_unique_batch_size=B, max_unique_seq_length=new + 16 + P, max_shared_batch_sizes=[1],
-                           max_shared_seq_lengths=[P], timing_only_alias_unique_cache=True)
+        _setup_caches_one_aliased_unique_buffer(model, B, new + 16 + P, [1], [P])
 
         def go(n):
             torch.cuda.synchronize()

@@ -221,8 +221,13 @@ class PerLayerKVCache(nn.Module):
                  n_kv_heads, head_dim, device, dtype):
         super().__init__()
         shape = (max_unique_batch_size, max_unique_seq_length, n_kv_heads, head_dim)
-        self.register_buffer("per_completion_k_cache", torch.zeros(shape, dtype=dtype, device=device))
-        self.register_buffer("per_completion_v_cache", torch.zeros(shape, dtype=dtype, device=device))
+        # One allocation, K | V: the suffix kernels stream a layer's unique K and V side by side, and two separate GiB-sized
+        # allocations land wherever the allocator puts them -- measured on MI355X (C5 whole job, grouped-query suffix kernel)
+        # the same binary runs at 180 us or 222 us from one process start to the next with two allocations, 180 us every time
+        # inside one arena.  The reference's two attribute names (llama.py:186-198) stay, as views.
+        arena = torch.zeros((2,) + shape, dtype=dtype, device=device)
+        self.register_buffer("per_completion_k_cache", arena[0])
+        self.register_buffer("per_completion_v_cache", arena[1])
         self.shared_caches = nn.ModuleList([
             SharedCache(b, s, n_kv_heads, head_dim, dtype, device)
             for b, s in zip(max_shared_batch_sizes, max_shared_seq_lengths)
@@ -664,33 +669,17 @@ class HydragenLlamaForCausalLM(nn.Module):
         return self.config.num_attention_heads
 
     def setup_caches(self, max_unique_batch_size: int, max_unique_seq_length: int,
-                     max_shared_batch_sizes: list[int], max_shared_seq_lengths: list[int],
-                     timing_only_alias_unique_cache: bool = False):
-        """Allocate the unique KV cache and the shared cache levels at every layer (llama.py:921-955).
-
-        timing_only_alias_unique_cache (not in the reference; bench.py's no-sharing leg): every layer's unique K/V cache is
-        ONE pair of buffers.  The generated tokens are meaningless then (the layers overwrite each other's keys), the time
-        per step is not: every layer still appends to and streams the whole buffer from HBM.  It is what lets the
-        no-sharing baseline (scripts/synth.py:112,151: the prefix replicated into every sequence's cache, 36 GB per LAYER at
-        batch 1024 / prefix 2048) run at the batch the headline is quoted on."""
+                     max_shared_batch_sizes: list[int], max_shared_seq_lengths: list[int]):
+        """Allocate the unique KV cache and the shared cache levels at every layer (llama.py:921-955)."""
         self.maybe_invalidate()
         max_unique_seq_length = (max_unique_seq_length + 15) // 16 * 16
-        first = None
         for layer in self.model.layers:
-            alias = timing_only_alias_unique_cache and first is not None
-            cache = PerLayerKVCache(
-                max_unique_batch_size=1 if alias else max_unique_batch_size,
-                max_unique_seq_length=16 if alias else max_unique_seq_length,
+            layer.self_attn.kv_cache = PerLayerKVCache(
+                max_unique_batch_size=max_unique_batch_size, max_unique_seq_length=max_unique_seq_length,
                 max_shared_batch_sizes=max_shared_batch_sizes, max_shared_seq_lengths=max_shared_seq_lengths,
                 n_kv_heads=self.config.num_key_value_heads,
                 head_dim=self.config.hidden_size // self.get_num_heads(),
                 device=self.lm_head.weight.device, dtype=self.lm_head.weight.dtype)
-            if alias:
-                cache.per_completion_k_cache = first.per_completion_k_cache
-                cache.per_completion_v_cache = first.per_completion_v_cache
-            elif first is None:
-                first = cache
-            layer.self_attn.kv_cache = cache
         self.kv_cache_allocated = True
 
     def empty_shared_cache(self):

@@ -58,6 +58,45 @@ def test_bench_two_ranks_without_a_launcher():
 
 
 @pytest.mark.gpu
+def test_bench_preflight_runs_every_stage_on_two_ranks():
+    """`--gpus 2` pre-flight (gloo, both ranks on cuda:0): devices, process group + checked 1 KiB all-reduce, peer access, one
+    hyd_allreduce_sum of 1 MiB over hipIpc checked against the group's result, agreement; the report rides on the line."""
+    env = dict(os.environ, HYD_BENCH_BACKEND="gloo", HYD_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--trials", "0",
+                        "--no-cpu-baseline", "--no-accuracy"], capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-3000:]
+    stages = [json.loads(ln[len("[preflight] "):]) for ln in r.stdout.splitlines() if ln.startswith("[preflight] ")]
+    assert [s_["stage"] for s_ in stages] == ["devices", "rccl_init", "peer_access", "xgmi_allreduce", "graph_collective", "agreement"]
+    assert all(s_["ok"] for s_ in stages), stages
+    assert stages[3]["bytes"] == 1 << 20 and stages[3]["max_abs_diff_vs_group"] < 0.1
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert set(res["preflight"]) == {s_["stage"] for s_ in stages} and res["value"] > 0
+    assert res["allreduce_xgmi"]["max_abs_diff_vs_rccl"] < 0.5  # the 8 MiB leg ran: the pre-flight left it switched on
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage,rc", [("peer_access", 3), ("xgmi_allreduce", 0)])
+def test_bench_preflight_names_the_failing_stage(stage, rc):
+    """A failing hard stage ends the job with an error line naming it and exit code 3; a failing xGMI stage only switches
+    that leg off and the headline still runs."""
+    env = dict(os.environ, HYD_BENCH_BACKEND="gloo", HYD_BENCH_ONE_DEVICE="1", HYD_BENCH_FAIL_STAGE=stage)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--trials", "0",
+                        "--no-cpu-baseline", "--no-accuracy"], capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if rc == 3:
+        assert r.returncode != 0 and lines, r.stderr[-2000:]
+        assert all(ln["preflight_stage"] == stage and stage in ln["error"] and ln["value"] is None for ln in lines)
+    else:
+        assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+        res = lines[0]
+        assert res["preflight"][stage]["ok"] is False and "allreduce_xgmi" not in res and res["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_c5_workload_on_two_ranks():
     """BASELINE config 5 as north_star states it (batch 2048, prefix 4096, 64 q / 8 kv heads, suffix 1..256), sharded over
     heads on two ranks (32 q / 4 kv heads each, tp.py:90-124) with the 32 MiB [2048, 1, 8192] all-reduce per step."""
@@ -105,7 +144,7 @@ def test_bench_single_gpu_line_is_complete():
     assert res["vs_baseline"] is None and res["dtype"] == "bf16" and res["data"] == "synthetic"
     assert len(res["trials"]["repeat_us_per_step"]) == 2
     assert abs(res["trials"]["trial0_us_per_step"] / (res["ms_per_step"] * 1e3) - 1) < 1e-4  # (nested figures carry 5 digits)
-    assert len(json.dumps(res)) < 8000 and res["detail_file"] == "profiles/bench_detail_latest.json"  # the driver keeps 8 KB
+    assert len(json.dumps(res)) < 8000 and res["detail_file"] == "gpurun_out/bench_detail.json"  # the driver keeps 8 KB
     detail = json.loads((REPO / res["detail_file"]).read_text())
     assert detail["value"] == res["value"] and "trials" in detail and "roofline_other" in detail
     assert set(res["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
@@ -156,7 +195,7 @@ def test_two_stream_policy_is_shapes_only():
 
 def test_compact_line_fits_the_drivers_record(tmp_path, monkeypatch):
     """The driver keeps the last 8 KB of bench.py's line: the line carries means at five digits, the per-point statistics
-    and the prose go to profiles/bench_detail_latest.json (round 3's 17 KB line lost roofline_other / trials / prefix_us)."""
+    and the prose go to the detail file (round 3's 17 KB line lost roofline_other / trials / prefix_us)."""
     import bench
 
     monkeypatch.setattr(bench, "DETAIL_FILE", tmp_path / "detail.json")

@@ -104,7 +104,8 @@ def main():
         if a.only and a.only not in name:
             continue
         r = lambda *s: torch.randn(*s, device=DEV, dtype=dt, generator=g)
-        q, k, v = r(B, 1, Hq, D), r(B, S, Hkv, D), r(B, S, Hkv, D)
+        q, kv = r(B, 1, Hq, D), r(2, B, S, Hkv, D)
+        k, v = kv[0], kv[1]  # one arena, K | V, as PerLayerKVCache allocates a layer's unique caches
         sks, svs = [r(sb, P, Hkv, D) for sb, P in levels], [r(sb, P, Hkv, D) for sb, P in levels]
         lens = torch.full((B,), S, dtype=torch.int32, device=DEV)
         hyd = lambda: hydragen_attention_nopad(q, k, v, sks, svs, seq_len=lens)

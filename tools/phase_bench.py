@@ -4,7 +4,7 @@
     python tools/phase_bench.py [--iters 30] [--only C3]
 
 For each shape: the one-call form (HYD_PHASE_ALL) and its two phases issued separately (HYD_PHASE_SHARED = the prefix
-pass incl. the in-launch merge of its split-KV slices, HYD_PHASE_UNIQUE = the suffix pass + LSE merge), each timed with HIP
+pass, HYD_PHASE_UNIQUE = the suffix pass + the merge with the prefix slices), each timed with HIP
 events call by call, back to back and cold (512 MB written + 512 MB read before every call).  Also the plan of the
 prefix pass (splits, grid)."""
 import argparse
@@ -68,7 +68,8 @@ def main():
             continue
         D, dt = 128, torch.bfloat16
         r = lambda *s: torch.randn(*s, device=DEV, dtype=dt, generator=g)
-        q, k, v, sk, sv = r(B, 1, Hq, D), r(B, S, Hkv, D), r(B, S, Hkv, D), r(1, P, Hkv, D), r(1, P, Hkv, D)
+        q, kv, sk, sv = r(B, 1, Hq, D), r(2, B, S, Hkv, D), r(1, P, Hkv, D), r(1, P, Hkv, D)
+        k, v = kv[0], kv[1]  # one arena, K | V, as PerLayerKVCache allocates a layer's unique caches
         lens = torch.full((B,), S, dtype=torch.int32, device=DEV)
         out = torch.empty_like(q)
         p = DecodeParams()

@@ -40,7 +40,8 @@ def main():
     D, dt = 128, torch.bfloat16
     g = torch.Generator(device=DEV).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=DEV, dtype=dt, generator=g)
-    q, k, v, sk, sv = r(B, 1, Hq, D), r(B, S, Hkv, D), r(B, S, Hkv, D), r(1, P, Hkv, D), r(1, P, Hkv, D)
+    q, kv, sk, sv = r(B, 1, Hq, D), r(2, B, S, Hkv, D), r(1, P, Hkv, D), r(1, P, Hkv, D)
+    k, v = kv[0], kv[1]  # one arena, K | V, as PerLayerKVCache allocates a layer's unique caches
     lens = torch.full((B,), S, dtype=torch.int32, device=DEV)
     out = torch.empty_like(q)
     p = DecodeParams()

@@ -31,5 +31,5 @@ done
 python $REPO/tools/make_traffic.py $OUT/${TAG}_pmc.txt $TAG $STEPS $WARM > $OUT/traffic_latest.json
 cd $REPO
 cp $OUT/traffic_latest.json $REPO/profiles/traffic_latest.json
-python bench.py --steps $STEPS --warmup $WARM > $OUT/${TAG}_bench.json 2>$OUT/${TAG}_bench.err
+python bench.py --steps $STEPS --warmup $WARM --detail-out $OUT/${TAG}_bench_detail.json > $OUT/${TAG}_bench.json 2>$OUT/${TAG}_bench.err
 tail -c 2500 $OUT/${TAG}_bench.json
