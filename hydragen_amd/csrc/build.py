@@ -23,6 +23,20 @@ if os.environ.get("HYD_ABLATION_BUILD"):  # development only: A/B switches, timi
     FLAGS.append("-DHYD_ABLATION_BUILD")
 
 
+def _includes(src: str, seen=None) -> list:
+    """The project headers a source includes, transitively (so that a kernel's object is rebuilt for ITS headers only)."""
+    import re
+
+    seen = set() if seen is None else seen
+    for inc in re.findall(r'^\s*#include\s+"([^"]+)"', (HERE / src).read_text(), flags=re.M):
+        path = (HERE / src).parent / inc
+        rel = os.path.relpath(path.resolve(), HERE)
+        if path.exists() and rel not in seen:
+            seen.add(rel)
+            _includes(rel, seen)
+    return sorted(seen)
+
+
 def _stale(target: Path, deps) -> bool:
     if not target.exists():
         return True
@@ -32,7 +46,7 @@ def _stale(target: Path, deps) -> bool:
 
 def _compile(src: str, force: bool) -> Path:
     obj = HERE / (Path(src).stem + ".o")
-    if force or _stale(obj, [src] + HEADERS + ["build.py"]):
+    if force or _stale(obj, [src] + _includes(src) + ["build.py"]):
         cmd = [HIPCC, *FLAGS, "-c", str(HERE / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -56,7 +70,7 @@ def _regcheck(src: str, force: bool) -> None:
     from regcheck import check_prefix_asm  # (build.py runs as a script and as hydragen_amd.csrc.build: plain import by path)
 
     stamp = _stamp(src)
-    if not (force or _stale(stamp, [src] + HEADERS + ["build.py", "regcheck.py"])):
+    if not (force or _stale(stamp, [src] + _includes(src) + ["build.py", "regcheck.py"])):
         return
     stamp.unlink(missing_ok=True)
     cmd = [HIPCC, *[f for f in FLAGS if f not in ("-fPIC", "-Werror")], "-S", "--cuda-device-only", str(HERE / src), "-o", "-"]

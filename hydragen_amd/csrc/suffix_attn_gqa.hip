@@ -37,8 +37,14 @@ namespace hyd {
 // (m, l, O) merged through LDS at the end -- for shapes with too few units to fill the chip with one wave each (C3: 1024
 // units on 256 CUs, C5: 2048), where nothing but more waves hides the per-step load latency.
 // NT: K/V loads carry the non-temporal hint (suffix_gqa_common.h): the unique phase, where every key is read once.
-template <typename T, int D, int WPU, bool NT>
-__global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+// HPW: kv heads per workgroup (WPU = 1 only).  The HPW one-wave units of a workgroup are the kv heads hk0 .. hk0 + HPW - 1 of ONE
+// sequence: they start together, have the same length and walk the same tokens, so the 256-byte pieces they read of every
+// token's [Hkv, D] row are requested together -- whole DRAM pages instead of one eighth of a page per visit (the one-wave
+// workgroups of a sequence's heads are 2048 workgroups apart in dispatch order).  No wave talks to another.
+template <typename T, int D, int WPU, bool NT, int HPW = 1>
+__global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(2, 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+    static_assert(WPU == 1 || HPW == 1, "several heads per workgroup: one-wave units only");
+    constexpr int NWV = WPU * HPW;  // waves per workgroup
     // every field a wave needs (and partials[0]) sits in the first 256 bytes of SuffixArgs: one scalar-cache miss at the start of
     // a unit's dependent chain (C5 slice 7.17 -> 7.00 us at S = 16, 25.6 -> 24.9 at S = 128 in an A/B within one run; the dot-product
     // kernel, whose 32768 waves all pay the four extra loads, lost 2-7 % at S <= 4 with it and does not have it)
@@ -51,14 +57,27 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key V tile
     constexpr int TILE = 32 * RB;    // bytes of one 32-key V tile (= 16 rows * D floats: reused by the merge)
     constexpr int NLD = 2 * NCH + NVD;  // vector-memory instructions per step (K fragments + V DMA)
-    __shared__ __attribute__((aligned(1024))) char vtiles[WPU][2][TILE];
-    __shared__ float mlx[WPU][4][16];
-    const int wave = WPU == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    char* vtile = vtiles[wave][0];
+    // dynamic LDS (8 heads per workgroup are 128 KB): [NWV waves][2 V tiles], then the merge's [NWV][4][16] floats
+    extern __shared__ __attribute__((aligned(1024))) char gqa_smem[];
+    char(*vtiles)[2][TILE] = reinterpret_cast<char(*)[2][TILE]>(gqa_smem);
+    float(*mlx)[4][16] = reinterpret_cast<float(*)[4][16]>(gqa_smem + NWV * 2 * TILE);
+    const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave of the workgroup
+    const int wave = WPU == 1 ? 0 : wv;                                                      // wave of the unit
+    char* vtile = vtiles[wv][0];
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g4 = lane >> 4;
-    const int b = blockIdx.x, hk = blockIdx.y, row0 = blockIdx.z * 16;
+    // workgroup -> (sequence, kv-head group): blockIdx.x runs over B * (Hkv / HPW) pairs in the order the host picked
+    const int ngrp = a.Hkv / HPW;
+    int b, hkg;
+    if (a.gqa_hk_fastest) {
+        b = (int)blockIdx.x / ngrp;
+        hkg = (int)blockIdx.x - b * ngrp;
+    } else {
+        hkg = (int)blockIdx.x / a.B;
+        b = (int)blockIdx.x - hkg * a.B;
+    }
+    const int hk = hkg * HPW + (HPW == 1 ? 0 : wv), row0 = blockIdx.y * 16;
 
     int len = a.kv_len;
     if (a.sl32) len = a.sl32[b];
@@ -124,22 +143,32 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float sc = a.scale_log2e;
 
     // ---- prefix partials (attention.py:21-43) are dealt to the unit's waves: wave w folds partials w, w + WPU, ... into
-    // its own (m, l, O) state after its keys -- a normalised partial (O_p, lse_p) IS the state (m = lse_p * log2 e, l = 1,
-    // O = O_p) -- and the merge of the waves then combines everything; no partial is left for the final epilogue.  The
-    // wave's first partial, when it is a 16-bit one (the usual single unsplit prefix level), is fetched here, under the
-    // K/V stream.  (These loads are older than every asm-issued one: the counted waits of the loop stay exact.)
+    // its own (m, l, O) state -- a normalised partial (O_p, lse_p) IS a state (m = lse_p * log2 e, l = 1, O = O_p) -- and the
+    // merge of the waves then combines everything; no partial is left for the final epilogue.  They ride UNDER the K/V stream:
+    // the wave's k-th partial is requested (into the asm-owned buffer a[64:96]) right after the (k-1)-th was folded and before
+    // step k-1 is computed, i.e. between the loads of key steps k and k+1 -- the counted wait in front of step k covers it,
+    // and it is folded there.  A split prefix level's fp32 slices (C3: 16, C5 slice: 2) thus cost no round trip of their own
+    // as long as the wave has key steps left; what remains is fetched behind the loop, two per round trip.  Not when the
+    // suffix pass's own LSE is asked for (a.lse: the unfused form), which needs the keys-only state at the end.
+    claim_partial_buffer();
     const int np = a.n_partials;
-    const bool pre = wave < np && !a.partials[wave].is_f32;
-    float pre_lse = -INFINITY;
-    u32x2 pre_u[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) pre_u[db] = u32x2{0u, 0u};
-    if (pre) {
-        pre_lse = a.partials[wave].lse[ridx];
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-            pre_u[db] = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.partials[wave].out) + ridx * D + 16 * db + 4 * g4);
-    }
+    const bool early = a.lse == nullptr;
+    int kp = 0;             // partials of this wave already folded (its k-th partial is number wave + k * WPU)
+    bool p_flying = false;  // partial kp is in flight to a[64:96]
+    auto request_partial = [&]() __attribute__((always_inline)) {
+        const int i = wave + kp * WPU;
+        if (!early || i >= np) return;
+        const PartialDev& pd = a.partials[i];
+        if (pd.is_f32) {
+            const float* po = static_cast<const float*>(pd.out) + ridx * D + 4 * g4;
+            static_for_g<NDB>([&](auto DB_) { PReg<decltype(DB_)::value>::load_f32(po + 16 * decltype(DB_)::value); });
+        } else {
+            const uint16_t* po = static_cast<const uint16_t*>(pd.out) + ridx * D + 4 * g4;
+            static_for_g<NDB>([&](auto DB_) { PReg<decltype(DB_)::value>::load_b16(po + 16 * decltype(DB_)::value); });
+        }
+        preg_load_lse(pd.lse + ridx);
+        p_flying = true;
+    };
 
     // all vector-memory instructions of one step: K fragments into register set BUF, V tile into LDS tile BUF
     auto issue = [&](auto BUF_, int key0) __attribute__((always_inline)) {
@@ -197,43 +226,7 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
         // are read by plain VALU code next (the rescale of the next step, the epilogue): drain the matrix pipeline
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     };
-    for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline (its last wait is vmcnt(0))
-        using std::integral_constant;
-        if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_len = a.p_len; }
-        else { krs_c = krs; vrs_c = vrs; seg_len = len; }
-        constexpr int stride = 32 * WPU;
-        const int k_first = wave * 32;
-        const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
-        auto key_of = [&](int j) { return k_first + j * stride; };
-        if (nst > 0) {
-            issue(integral_constant<int, 0>{}, key_of(0));
-            for (int j = 0;;) {
-                bool more = j + 1 < nst;
-                if (more) {
-                    issue(integral_constant<int, 1>{}, key_of(j + 1));
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");  // step j landed, step j+1 in flight
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                step(integral_constant<int, 0>{}, key_of(j));
-                if (!more) break;
-                ++j;
-                more = j + 1 < nst;
-                if (more) {
-                    issue(integral_constant<int, 0>{}, key_of(j + 1));
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                step(integral_constant<int, 1>{}, key_of(j));
-                if (!more) break;
-                ++j;
-            }
-        }
-    }
-
-    // ---- fold this wave's share of the prefix partials ------------------------------------------------------------
-    const float m_s = m_run, l_s = l_run;  // the suffix-only state: the LSE output is the suffix pass's own
+    // ---- folding a prefix partial into this wave's state -----------------------------------------------------------------
     auto fold = [&](float lse_p, const f32x4(&x)[NDB]) __attribute__((always_inline)) {
         const float m_p = lse_p * 1.4426950408889634f;
         const float mf = fmaxf(m_run, m_p);
@@ -261,12 +254,76 @@ __global__ __launch_bounds__(64 * WPU) __attribute__((amdgpu_waves_per_eu(2, 2))
             widen(u, x);
         }
     };
-    if (pre) {
+    // the partial in a[64:96] has landed (the caller waited): read it back, fold it
+    auto take_partial = [&]() __attribute__((always_inline)) {
+        const bool f32 = a.partials[wave + kp * WPU].is_f32 != 0;
         f32x4 x[NDB];
-        widen(pre_u, x);
-        fold(pre_lse, x);
+        static_for_g<NDB>([&](auto DB_) {
+            constexpr int db = decltype(DB_)::value;
+            const unsigned w0 = PReg<db>::template read<0>(), w1 = PReg<db>::template read<1>();
+            if (f32) {
+                const unsigned w2 = PReg<db>::template read<2>(), w3 = PReg<db>::template read<3>();
+                x[db] = f32x4{__builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1), __builtin_bit_cast(float, w2), __builtin_bit_cast(float, w3)};
+            } else {
+                x[db] = f32x4{TR::lo(w0), TR::hi(w0), TR::lo(w1), TR::hi(w1)};
+            }
+        });
+        fold(preg_read_lse(), x);
+        ++kp;
+        p_flying = false;
+    };
+    for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline (its last wait is vmcnt(0))
+        using std::integral_constant;
+        if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_len = a.p_len; }
+        else { krs_c = krs; vrs_c = vrs; seg_len = len; }
+        constexpr int stride = 32 * WPU;
+        const int k_first = wave * 32;
+        const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
+        auto key_of = [&](int j) { return k_first + j * stride; };
+        if (nst > 0) {
+            issue(integral_constant<int, 0>{}, key_of(0));
+            if (!p_flying) request_partial();  // younger than step 0's loads, older than step 1's
+            for (int j = 0;;) {
+                bool more = j + 1 < nst;
+                if (more) {
+                    issue(integral_constant<int, 1>{}, key_of(j + 1));
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");  // step j (and the partial behind it) landed, step j+1 in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (p_flying) {
+                    take_partial();
+                    request_partial();
+                }
+                step(integral_constant<int, 0>{}, key_of(j));
+                if (!more) break;
+                ++j;
+                more = j + 1 < nst;
+                if (more) {
+                    issue(integral_constant<int, 0>{}, key_of(j + 1));
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (p_flying) {
+                    take_partial();
+                    request_partial();
+                }
+                step(integral_constant<int, 1>{}, key_of(j));
+                if (!more) break;
+                ++j;
+            }
+        }
     }
-    for (int i = wave + (pre ? WPU : 0); i < np; i += 2 * WPU) {
+    // the keys-only state (the LSE output is the suffix pass's own; when it is asked for, no partial was folded above)
+    const float m_s = m_run, l_s = l_run;
+    if (p_flying) {  // requested in front of the last step: landed under its arithmetic
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        take_partial();
+    }
+
+    // ---- this wave's partials that found no key step to ride under ----------------------------------------------------
+    for (int i = wave + kp * WPU; i < np; i += 2 * WPU) {
         // two partials per round trip: their lse values and 2 * D/16 row pieces are all requested before the first use
         const bool two = i + WPU < np;
         const int i1 = two ? i + WPU : i;
@@ -339,33 +396,48 @@ bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
     return span < (int64_t)1 << 31 && a.Hkv <= 65535 && chunks <= 65535;
 }
 
+template <typename T, int D, int WPU, bool NT, int HPW>
+static int launch_gqa_k(const SuffixArgs& a, dim3 grid, size_t pad, hipStream_t s) {
+    constexpr int NWV = WPU * HPW;
+    constexpr size_t lds = (size_t)NWV * 2 * 32 * D * 2 + (size_t)NWV * 4 * 16 * sizeof(float);
+    auto kern = suffix_attn_gqa_kernel<T, D, WPU, NT, HPW>;
+    // once per instantiation, thread-safe (C++11 static initialisation)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (attr_rc != hipSuccess) return (int)attr_rc;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds + pad, s, a);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int D>
-static int launch_gqa_t(const SuffixArgs& a, hipStream_t s) {
+static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
+    SuffixArgs a = a_in;
     const int chunks = (a.rows + 15) / 16;
     // shapes only: fewer than 4 one-wave units per CU (measured: B=32, 8/1 heads, 1152 keys 48 -> 31 us; at 1024 and
     // 2048 units -- C3, C5 -- one wave per unit is as fast or faster), and enough keys to deal out
     bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len + (a.pk ? a.p_len : 0) >= 128;
+    int hpw = 1;  // kv heads of a sequence per workgroup: one-wave units of the unique phase with several kv heads
+    if (!few_units && !a.shared_kv && !a.pk) hpw = a.Hkv % 8 == 0 ? 8 : a.Hkv % 4 == 0 ? 4 : a.Hkv % 2 == 0 ? 2 : 1;
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
+    if (const char* e = getenv("HYD_GQA_HPW")) hpw = few_units ? 1 : atoi(e);
+    if (const char* e = getenv("HYD_GQA_ORDER")) a.gqa_hk_fastest = atoi(e);
 #endif
-    dim3 grid(a.B, a.Hkv, chunks);
+    dim3 grid((unsigned)a.B * (unsigned)(a.Hkv / hpw), chunks, 1);
     size_t pad = 0;  // development: dynamic LDS that only lowers the occupancy (waves per CU = 160 KiB / (16 KiB + pad))
 #ifdef HYD_ABLATION_BUILD
-    if (const char* e = getenv("HYD_GQA_LDS_PAD")) {
-        pad = (size_t)atoi(e);
-        static const hipError_t rc_ = hipFuncSetAttribute(reinterpret_cast<const void*>(suffix_attn_gqa_kernel<T, D, 1, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        (void)rc_;
-    }
+    if (const char* e = getenv("HYD_GQA_LDS_PAD")) pad = (size_t)atoi(e);
 #endif
     if (a.shared_kv) {  // a small shared level: its keys are read by several workgroups, default cache policy
-        if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1, false>), grid, dim3(64), pad, s, a);
-    } else {
-        if (few_units) hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 4, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((suffix_attn_gqa_kernel<T, D, 1, true>), grid, dim3(64), pad, s, a);
+        if (few_units) return launch_gqa_k<T, D, 4, false, 1>(a, grid, 0, s);
+        return launch_gqa_k<T, D, 1, false, 1>(a, grid, pad, s);
     }
-    return (int)hipGetLastError();
+    if (few_units) return launch_gqa_k<T, D, 4, true, 1>(a, grid, 0, s);
+    switch (hpw) {
+        case 8: return launch_gqa_k<T, D, 1, true, 8>(a, grid, 0, s);
+        case 4: return launch_gqa_k<T, D, 1, true, 4>(a, grid, 0, s);
+        case 2: return launch_gqa_k<T, D, 1, true, 2>(a, grid, 0, s);
+        default: return launch_gqa_k<T, D, 1, true, 1>(a, grid, pad, s);
+    }
 }
 
 int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s) {

@@ -86,6 +86,36 @@ HYD_KREG(8, 32, 33, 34, 35) HYD_KREG(9, 36, 37, 38, 39) HYD_KREG(10, 40, 41, 42,
 HYD_KREG(12, 48, 49, 50, 51) HYD_KREG(13, 52, 53, 54, 55) HYD_KREG(14, 56, 57, 58, 59) HYD_KREG(15, 60, 61, 62, 63)
 #undef HYD_KREG
 
+// Partial-prefetch buffer a[64:96], asm-owned like the K sets: one prefix partial's row piece of this lane -- dims
+// [16 db + 4 g4, +4) in a[64 + 4 db : 67 + 4 db] (fp32; a 16-bit partial fills a[64 + 4 db : 65 + 4 db]) and its LSE in a[96] --
+// loaded under the K/V stream and read back (v_accvgpr_read) after the counted wait that covers it.
+__device__ __forceinline__ void claim_partial_buffer() {
+    asm volatile("" ::: "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80",
+                 "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96");
+}
+template <int DB>
+struct PReg {
+    static constexpr int R0 = 64 + 4 * DB;
+    static __device__ __forceinline__ void load_f32(const float* p) {  // 16 B: four fp32 dims
+        asm volatile("global_load_dwordx4 a[%1:%2], %0, off" ::"v"(p), "n"(R0), "n"(R0 + 3) : "memory");
+    }
+    static __device__ __forceinline__ void load_b16(const uint16_t* p) {  // 8 B: four 16-bit dims
+        asm volatile("global_load_dwordx2 a[%1:%2], %0, off" ::"v"(p), "n"(R0), "n"(R0 + 1) : "memory");
+    }
+    template <int J>
+    static __device__ __forceinline__ unsigned read() {
+        unsigned x;
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(R0 + J));
+        return x;
+    }
+};
+__device__ __forceinline__ void preg_load_lse(const float* p) { asm volatile("global_load_dword a96, %0, off" ::"v"(p) : "memory"); }
+__device__ __forceinline__ float preg_read_lse() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a96" : "=v"(x));
+    return x;
+}
+
 template <int N, typename F>
 __device__ __forceinline__ void static_for_g(F&& f) {
     if constexpr (N > 0) {

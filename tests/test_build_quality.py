@@ -143,7 +143,8 @@ def test_gqa_suffix_kernel_owns_its_k_registers_while_loads_are_in_flight():
             inasm = False
         elif t and not t.startswith((";", ".", "//")) and re.search(r"\ba\[?\d", t.split(";")[0]):
             kernels[cur]["asm" if inasm else "comp"].append((n, t))
-    assert len(kernels) == 16, sorted(kernels)  # {f16, bf16} x {64, 128} x {1, 4 waves per unit} x {non-temporal K/V or not}
+    # {f16, bf16} x {64, 128} x ({1, 4 waves per unit} x {non-temporal K/V or not} + {2, 4, 8 kv heads per workgroup})
+    assert len(kernels) == 28, sorted(kernels)
     for name, v in kernels.items():
         assert v["asm"], name
         lo, hi = v["asm"][0][0], v["asm"][-1][0]

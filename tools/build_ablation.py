@@ -13,9 +13,13 @@ srcs = ["api.hip", "prefix_attn_w64.hip", "prefix_attn_w64_f16.hip", "suffix_att
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DHYD_ABLATION_BUILD", "-Wno-unused-function"]
 
 
+sys.path.insert(0, str(src))
+from build import _includes  # noqa: E402  (the product build's include scanner: rebuild an object for ITS headers only)
+
+
 def cc(f):
     o = out / (Path(f).stem + ".o")
-    if o.exists() and o.stat().st_mtime > max([(src / f).stat().st_mtime] + [h.stat().st_mtime for h in src.glob("*.h")]):
+    if o.exists() and o.stat().st_mtime > max([(src / f).stat().st_mtime] + [(src / h).stat().st_mtime for h in _includes(f)]):
         return str(o)
     r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-c", str(src / f), "-o", str(o)], capture_output=True, text=True)
     if r.returncode:

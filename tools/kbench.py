@@ -22,6 +22,9 @@ ap.add_argument("--D", type=int, default=128)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--splits", type=int, default=0, help="0 = the library's own split-KV plan")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--kv-gap", type=int, default=0, help="suffix: bytes between the end of K and the start of V in their arena (-1: two allocations)")
+ap.add_argument("--smax", type=int, default=0, help="suffix: token rows of the cache allocation (default: the largest --S)")
+ap.add_argument("--pad-tokens", type=int, default=0, help="suffix: extra token rows per sequence in the cache allocation (batch stride (S + pad) rows)")
 a = ap.parse_args()
 lib = _lib.load()
 dev = "cuda:0"
@@ -62,8 +65,13 @@ if a.what == "prefix":
                 d = [(int(ts[w, k]) - int(ts[w, 0])) & 0xffffffff for k in range(6)]
                 print(f"   wave {w}: setup+issue {d[1]}  first wait+barrier {d[2]-d[1]}  loop {d[3]-d[2]}  merge write+barrier {d[4]-d[3]}  combine+stores {d[5]-d[4]}  | kernel {d[5]} ticks")
 else:
-    Smax = max(map(int, a.S.split(",")))
-    k = torch.randn(a.B, Smax, a.Hkv, a.D, device=dev, dtype=dt); v = torch.randn_like(k)
+    Smax = max(max(map(int, a.S.split(","))), a.smax)
+    n_ = a.B * (Smax + a.pad_tokens) * a.Hkv * a.D
+    if a.kv_gap < 0:  # two separate allocations
+        k = torch.randn(a.B, Smax + a.pad_tokens, a.Hkv, a.D, device=dev, dtype=dt)[:, :Smax]; v = torch.randn(a.B, Smax + a.pad_tokens, a.Hkv, a.D, device=dev, dtype=dt)[:, :Smax]
+    else:  # one arena, K | gap | V (PerLayerKVCache allocates K | V)
+        arena = torch.randn(2 * n_ + a.kv_gap // 2, device=dev, dtype=dt)
+        k = arena[:n_].view(a.B, Smax + a.pad_tokens, a.Hkv, a.D)[:, :Smax]; v = arena[n_ + a.kv_gap // 2:].view(a.B, Smax + a.pad_tokens, a.Hkv, a.D)[:, :Smax]
     out = torch.empty_like(q); lse = torch.empty(a.B, 1, a.Hq, device=dev, dtype=torch.float32)
     pout = torch.randn_like(q); plse = torch.randn(a.B, 1, a.Hq, device=dev, dtype=torch.float32)
     for S in map(int, a.S.split(",")):
