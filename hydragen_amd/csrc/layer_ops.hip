@@ -143,10 +143,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 // standard Gumbel noise from 23 random bits: u = (k + 1/2) 2^-23 for k in [0, 2^23), strictly inside (0, 1) and exact in
 // fp32 (24 significant bits).  (The former 24-bit form (k 2^-24 + 2^-25) rounded to exactly 1.0 for k = 2^24 - 1 -- a tie
 // that rounds to even -- where -ln u = 0 and the noise is +inf: that column won the argmax whatever its logit, about two
-// tokens per decode step at a batch of 1024 and a vocabulary of 32000.)  g = -ln(-ln u), finite for every k.
+// tokens per decode step at a batch of 1024 and a vocabulary of 32000.)  g = -ln(-ln u), finite for every k -- also on
+// hardware whose approximate log2 returns 0 for the largest u (1 - 2^-24, true -ln u = 2^-24): -ln u is held at >= 2^-25.
 __device__ __forceinline__ float gumbel(uint32_t bits) {
     const float u = ((float)(bits >> 9) + 0.5f) * 0x1p-23f;
-    return -kLn2 * fast_log2(-kLn2 * fast_log2(u));
+    const float e = fmaxf(-kLn2 * fast_log2(u), 0x1p-25f);
+    return -kLn2 * fast_log2(e);
 }
 
 }  // namespace

@@ -3,23 +3,32 @@
 // gfx950 matrix cores.  Replaces flash-attn's _flash_attn_forward / _flash_attn_varlen_forward as called from
 // /root/reference/hydragen/flash.py:284-351 and hydragen/attention.py:270,313,344.
 //
-// Work decomposition (one wave per SIMD, the whole 512-entry register file per wave):
-//   workgroup = 256 threads = 4 waves; every wave owns 64 folded query rows (b_local, iq, gqa head) = two 32-row
-//   query blocks, so each K / V^T fragment read from LDS feeds TWO MFMAs (half the LDS, DMA and address traffic per
-//   flop of a 32-row wave) and the two blocks' softmax chains interleave in the MFMA shadow.
-//   KG = 2: 128 rows per workgroup, wave = (64-row half, key half of every 128-key tile); the two key halves keep
+// Work decomposition: one unit body, two wave geometries over the SAME rows per workgroup, LDS rings and pipeline (NW below):
+//   NW = 8 (the default for D = 128): 512 threads = 8 waves, two per SIMD, 32 folded query rows (b_local, iq, gqa head) per
+//           wave, 256 registers per wave, O / Q in the literal VGPRs v[160:255] (RegsV); the SIMD issues one wave's VALU /
+//           LDS / DMA instructions beside the other wave's MFMAs.
+//   NW = 4 (D = 64 / 256, persistent launches): 256 threads = 4 waves, one per SIMD, 64 rows = two 32-row query blocks per
+//           wave, so that each K / V^T fragment read from LDS feeds TWO MFMAs and the two blocks' softmax chains interleave
+//           in the MFMA shadow; 512 registers per wave, O / Q in the literal AGPRs a[0:191] (RegsA).
+//   KG = 2: 128 rows per workgroup, wave = (row sub-block, key half of every 128-key tile); the two key halves keep
 //           independent (m, l, O) and are merged through LDS at the end.
 //   KG = 1: 256 rows per workgroup, every wave walks all keys (shapes with enough rows to fill the chip that way).
 //   S^T = K.Q^T and O^T += V^T.P^T with v_mfma_f32_32x32x16: computing the transposed products puts one query row per
 //   lane, so the softmax reductions are in-lane plus one v_permlane32_swap, and P^T is already the B operand.
 //
 // Pipeline (per wave, over 32-key blocks b): iteration i interleaves, instruction by instruction,
-//   MFMA stream: QK(i+1) and PV(i-1), alternating, each fragment used by both query blocks
-//   VALU stream: online softmax of block i for both query blocks (max3 tree, exp2, row sums, pack to 16-bit P^T)
-// with the order pinned by sched_barriers; the running maximum is only raised when a block exceeds it by more than
-// 2^kTau (the O rescale is a cold wave-uniform branch).  K and V live in LDS rings of four 32-key block slots filled by
-// LDS-DMA (buffer_load ... lds, zero fill past the end of the keys): iteration i issues K block i+4 and V block i+2
-// and its barrier only waits for the DMAs issued during iteration i-1.
+//   MFMA stream: QK(i+1) and PV(i-1), alternating
+//   VALU stream: online softmax of block i (exp2, row sums, pack to 16-bit P^T), one group of 4-5 instructions behind
+//                every MFMA, the order pinned by sched_barriers
+// The running maximum is only raised when a block exceeds it by more than 2^kTau (the O rescale is a cold wave-uniform
+// branch): NW = 4 tests the block's maximum (max3 tree) against a threshold; NW = 8 has no maximum tree at all -- it tests
+// the lane's SUM of the block's probabilities (LAZY, see the iteration) and recomputes the block on the cold path.
+// K and V live in LDS rings of four 32-key block slots filled by LDS-DMA (buffer_load ... lds, zero fill past the end of
+// the keys): iteration i issues K block i+4 and V block i+2 and its barrier only waits for the DMAs issued during
+// iteration i-1.
+// Register ownership (the contract tests/test_build_quality.py and csrc/regcheck.py enforce): the asm statements of RegsV /
+// RegsA name their registers literally and carry no operands for them; hipcc is kept out by the kernels' register budgets
+// (prefix_launch_w64.h) and because nothing spills.
 #include <type_traits>
 #include <utility>
 
@@ -94,16 +103,10 @@ __device__ __forceinline__ void dma_wait_w() { asm volatile("s_waitcnt vmcnt(%0)
 // definition serves the 8 O blocks and the 16 Q fragments.  These statements carry no clobber lists; claim_agprs()
 // below names a[0:191] once per unit, which is what sizes the kernel descriptor's accumulator file.
 #define HYD_A10(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
-template <int N>
-__device__ __forceinline__ void claim_agprs() {
-    static_assert(N == 96 || N == 192, "accumulator registers of a unit");
-    if constexpr (N == 192)
-        asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
-                     HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), HYD_A10(9), HYD_A10(10), HYD_A10(11), HYD_A10(12), HYD_A10(13),
-                     HYD_A10(14), HYD_A10(15), HYD_A10(16), HYD_A10(17), HYD_A10(18), "a190", "a191");
-    else
-        asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
-                     HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), "a90", "a91", "a92", "a93", "a94", "a95");
+__device__ __forceinline__ void claim_agprs() {  // a[0:191] of the 4-wave unit
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", HYD_A10(1), HYD_A10(2), HYD_A10(3), HYD_A10(4),
+                 HYD_A10(5), HYD_A10(6), HYD_A10(7), HYD_A10(8), HYD_A10(9), HYD_A10(10), HYD_A10(11), HYD_A10(12), HYD_A10(13),
+                 HYD_A10(14), HYD_A10(15), HYD_A10(16), HYD_A10(17), HYD_A10(18), "a190", "a191");
 }
 #undef HYD_A10
 #define HYD_IRP16 ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\t"
@@ -138,9 +141,9 @@ struct OAcc {  // O block I = qb * NDB + db: a[16 I : 16 I + 15]
     }
 };
 
-template <int I, int QBASE>
-struct QFrag {  // Q fragment I = qb * NC + c: a[QBASE + 4 I : QBASE + 3 + 4 I]
-    static constexpr int R0 = QBASE + 4 * I;
+template <int I>
+struct QFrag {  // Q fragment I = qb * NC + c: a[128 + 4 I : 131 + 4 I]
+    static constexpr int R0 = 128 + 4 * I;
     template <int OFF>
     static __device__ __forceinline__ void load(const void* p) {
         asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(p), "n"(R0), "n"(R0 + 3), "n"(OFF) : "memory");
@@ -156,15 +159,11 @@ struct QFrag {  // Q fragment I = qb * NC + c: a[QBASE + 4 I : QBASE + 3 + 4 I]
 // every MFMA issued so far has written its result (8-pass XDL: 18 wait states cover any reader)
 __device__ __forceinline__ void acc_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 
-// Where the O accumulators and the Q fragments live: literal accumulator registers, O block I in a[16 I : 16 I + 15], Q
-// fragment I in a[QBASE + 4 I : QBASE + 4 I + 3]; NCLAIM registers are claimed for the kernel descriptor.
-//   one wave per SIMD (4-wave workgroups, 64-row waves or D = 256):  QBASE = 128, NCLAIM = 192 of the wave's 512 registers
-//   two waves per SIMD (8-wave workgroups, 32-row waves, D <= 128):  QBASE = 64,  NCLAIM = 96; hipcc then splits the 256
-//   registers of a wave 128 / 128 and fits its own values into 128 architectural VGPRs (no spills, no accumulator
-//   register of its own: tests/test_build_quality.py).
-template <int QBASE, int NCLAIM>
+// RegsA -- one wave per SIMD (4-wave workgroups; 64-row waves, or one 32-row block at D = 256): O block I lives in the literal
+// accumulator registers a[16 I : 16 I + 15], Q fragment I in a[128 + 4 I : 131 + 4 I]; a[0:191] of the wave's 512 registers are
+// claimed for the kernel descriptor.
 struct RegsA {
-    __device__ __forceinline__ void claim() { claim_agprs<NCLAIM>(); }
+    __device__ __forceinline__ void claim() { claim_agprs(); }
     template <int I, bool BF>
     __device__ __forceinline__ void pv(const u32x4& a, const u32x4& b) { OAcc<I>::template pv<BF>(a, b); }
     template <int I>
@@ -180,9 +179,9 @@ struct RegsA {
     template <int I>
     __device__ __forceinline__ void read(float (&x)[16]) { OAcc<I>::read(x); }
     template <int I, int OFF>
-    __device__ __forceinline__ void qload(const void* p) { QFrag<I, QBASE>::template load<OFF>(p); }
+    __device__ __forceinline__ void qload(const void* p) { QFrag<I>::template load<OFF>(p); }
     template <int I, bool BF, bool FIRST>
-    __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) { QFrag<I, QBASE>::template qk<BF, FIRST>(s, a); }
+    __device__ __forceinline__ void qk(f32x16& s, const u32x4& a) { QFrag<I>::template qk<BF, FIRST>(s, a); }
     __device__ __forceinline__ void drain() { acc_drain(); }
 };
 // RegsV -- two waves per SIMD (8-wave workgroups, 32-row waves, 256 registers per wave): no accumulator registers at all
@@ -311,16 +310,16 @@ constexpr int kElemGroupStartL[17] = {0, 4, 7, 10, 13, 16, 21, 23, 28, 30, 35, 3
 // (8 x 16) and Q fragments (16 x 4) fill the same a[0:191] that two blocks fill at D = 128 (then always KG = 1: 128
 // rows per workgroup, every wave walks all keys, 128 KB of rings).
 // PERSIST: the unit runs inside a persistent workgroup's unit loop (see dma16w's PAD).
-// NW: waves per workgroup.  4 = one wave per SIMD, 64-row waves (512 registers per wave); 8 = two waves per SIMD, 32-row
-// waves (256 registers per wave: 96 accumulator registers for O / Q + 128 of hipcc's): the same rows per workgroup, the
-// same rings, the same pipeline per wave -- half the MFMAs per wave and iteration, and the SIMD issues one wave's VALU /
+// NW: waves per workgroup.  4 = one wave per SIMD, 64-row waves (512 registers per wave, RegsA); 8 = two waves per SIMD, 32-row
+// waves (256 registers per wave, all architectural VGPRs: v[160:255] for O / Q (RegsV) + at most 160 of hipcc's): the same rows
+// per workgroup, the same rings, the same pipeline per wave -- half the MFMAs per wave and iteration, and the SIMD issues one wave's VALU /
 // LDS / DMA instructions in the shadow of the other wave's MFMAs (tests/probes/pingpong_probe.hip: 36.5 against 46.7 - 53
 // cycles per MFMA and SIMD for the instruction mix of this loop).
 template <typename T, int D, bool CAUSAL, int KG, int ABL = 0, bool PERSIST = false, int NW = 4, int QB = ((D > 128 || NW == 8) ? 1 : 2)>
 __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int vblock, const int vgrid, char* smem) {
     using TR = Traits<T>;
     static_assert(NW == 4 || (NW == 8 && QB == 1 && D <= 128), "two waves per SIMD: 32-row waves, D <= 128");
-    std::conditional_t<NW == 8, RegsV, RegsA<128, 192>> regs;
+    std::conditional_t<NW == 8, RegsV, RegsA> regs;
     regs.claim();
     if constexpr ((ABL & 4096) != 0) asm volatile("s_nop 0");  // development: shifts the whole stream by 4 bytes (code-placement probe)
     static_assert(QB == 1 || QB == 2, "query blocks per wave");

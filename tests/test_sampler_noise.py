@@ -18,6 +18,11 @@ def _u(bits: np.ndarray) -> np.ndarray:
 def test_uniform_variate_is_strictly_inside_the_unit_interval():
     text = SRC.read_text()
     assert re.search(r"const float u = \(\(float\)\(bits >> 9\) \+ 0\.5f\) \* 0x1p-23f;", text), "gumbel() changed: update this mirror"
+    # -ln u is clamped from below, so the noise is finite whatever the hardware's approximate log2 returns near u = 1
+    assert re.search(r"const float e = fmaxf\(-kLn2 \* fast_log2\(u\), 0x1p-25f\);", text), "gumbel() lost its clamp"
+    for sloppy_log in (0.0, -8.6e-8):  # log2(u) at the largest u: a sloppy unit may return exactly 0
+        e = max(-np.log(2.0) * sloppy_log, 2.0 ** -25)
+        assert np.isfinite(-np.log(e)) and -np.log(e) <= 17.4
     edge = np.array([0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFE00, 0xFFFFFFFF], dtype=np.uint32)
     rnd = np.random.default_rng(0).integers(0, 2 ** 32, size=1 << 20, dtype=np.uint64).astype(np.uint32)
     for bits in (edge, rnd):

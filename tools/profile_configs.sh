@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel-level rocprofv3 summaries of the grouped-query BASELINE configs (run through gpurun from the repo root):
+# Kernel-level rocprofv3 summaries of the BASELINE configs besides C2 (C3, C4, C5 slice, C5 whole job) (run through gpurun from the repo root):
 #   tools/profile_configs.sh r02_v4      -> gpurun_out/<tag>_gqa_kernel_stats.txt
 # One --kernel-trace --stats pass and one --pmc FETCH_SIZE pass per config (counter passes carry no trace domains).
 set -u
@@ -10,7 +10,7 @@ mkdir -p $REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 : > $OUT
-for C in "C3 (" "C5 TP"; do
+for C in "C3 (" "C4 two" "C5 TP" "C5 whole"; do
   CMD="python $REPO/tools/bench_configs.py --only \"$C\" --no-baseline --iters 20"
   rm -rf /tmp/pc_s /tmp/pc_f
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pc_s -o run -- python $REPO/tools/bench_configs.py --only "$C" --no-baseline --iters 20 > /tmp/pc_s.log 2>&1
@@ -21,6 +21,11 @@ for C in "C3 (" "C5 TP"; do
   timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/pc_f -o run -- python $REPO/tools/bench_configs.py --only "$C" --no-baseline --iters 20 > /tmp/pc_f.log 2>&1
   DB=$(find /tmp/pc_f -name '*.db' | head -1)
   echo "# rocprofv3 --pmc FETCH_SIZE (KB per launch; x2 on gfx950 per MI355X_MICROARCH.md)" >> $OUT
+  python $REPO/tools/rocprof_summary.py pmc $DB _attn >> $OUT
+  rm -rf /tmp/pc_w
+  timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/pc_w -o run -- python $REPO/tools/bench_configs.py --only "$C" --no-baseline --iters 20 > /tmp/pc_w.log 2>&1
+  DB=$(find /tmp/pc_w -name '*.db' | head -1)
+  echo "# rocprofv3 --pmc WRITE_SIZE (KB per launch)" >> $OUT
   python $REPO/tools/rocprof_summary.py pmc $DB _attn >> $OUT
   echo >> $OUT
 done
