@@ -55,7 +55,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape B,P,S,Hq,Hkv (repeatable), e.g. a TP rank's shard of C2: 1024,2048,128,4,4")
     a = ap.parse_args()
+    for sh in a.shape:
+        B_, P_, S_, Hq_, Hkv_ = map(int, sh.split(","))
+        SHAPES.append((f"custom (B={B_},P={P_},S={S_},{Hq_}/{Hkv_})", B_, P_, S_, Hq_, Hkv_))
     lib = _lib.load()
     flush = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=DEV)
     clean = torch.zeros(512 * 1024 * 1024 // 4, dtype=torch.int32, device=DEV)
