@@ -221,10 +221,9 @@ class PerLayerKVCache(nn.Module):
                  n_kv_heads, head_dim, device, dtype):
         super().__init__()
         shape = (max_unique_batch_size, max_unique_seq_length, n_kv_heads, head_dim)
-        # One allocation, K | V: the suffix kernels stream a layer's unique K and V side by side, and two separate GiB-sized
-        # allocations land wherever the allocator puts them -- measured on MI355X (C5 whole job, grouped-query suffix kernel)
-        # the same binary runs at 180 us or 222 us from one process start to the next with two allocations, 180 us every time
-        # inside one arena.  The reference's two attribute names (llama.py:186-198) stay, as views.
+        # One allocation, K | V (the reference's two attribute names, llama.py:186-198, stay as views).  Neutral for speed: round 4
+        # suspected that two separate GiB-sized allocations decide the grouped-query suffix kernel's rate; measured on four boxes in
+        # round 5, neither the arena nor any K-V gap or batch stride does (profiles/r05_gqa_placement.md).
         arena = torch.zeros((2,) + shape, dtype=dtype, device=device)
         self.register_buffer("per_completion_k_cache", arena[0])
         self.register_buffer("per_completion_v_cache", arena[1])
