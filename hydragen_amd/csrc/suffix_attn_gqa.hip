@@ -9,22 +9,20 @@
 // Why a second kernel: with R rows per unit the wave-level dot-product kernel issues ~R * 12 VALU instructions
 // per 4 keys and stops being HBM-bound at R = 8 (measured 2.1 TB/s at B = 2048, Hq/Hkv = 8/1, S = 256).  Here a
 // wave owns one unit and walks its keys 32 at a time:
-//   K  : 16-byte bounds-checked buffer loads straight into MFMA A-operand layout (lane = key & 15, 8 dims per
-//        lane), no LDS; keys past seq_len come back as zeros and are masked
+//   K, V: LDS-DMA (buffer_load ... lds: whole rows, zero fill past seq_len) into one swizzled 32-key landing tile each;
+//        once a step has landed its tiles are emptied into registers -- K as MFMA A operands (ds_read_b128), V^T with
+//        ds_read_b64_tr_b16 -- and handed straight to the next step's DMA
 //   S^T = K . Q^T      2 * D/32 x v_mfma_f32_16x16x32 (Q rows padded to 16, kept in registers)
 //   online softmax in base 2, one query row per lane & 15, 8 scores per lane, two cross-lane exchanges
-//   V  : LDS-DMA (buffer_load ... lds, zero fill past seq_len) into a swizzled 32-key tile, read back
-//        transposed with ds_read_b64_tr_b16
 //   O^T += V^T . P^T   D/16 x MFMA, P^T converted in registers (the contraction index is permuted to the
 //        accumulator layout, keys {4j..4j+3, 16+4j..}, so no data moves)
-// One wave per workgroup: producer and consumer of the LDS tile are the same wave, no barriers.
+// Producer and consumer of a wave's tiles are the same wave: no barriers.
 //
-// Software pipeline: the loads of step i+1 (K fragments and the V tile) are issued before step i is computed and the
-// wait in front of step i is a counted one (s_waitcnt vmcnt(<loads of step i+1>)), so a wave always has one to two
-// 16 KiB steps in flight.  That takes two K register sets and two LDS tiles.  The K sets live in literal AGPRs
-// a[0:63], named only by this file's asm statements (the loads that fill them and the QK MFMAs that read them as the A
-// operand): a compiler-allocated destination of an asm-issued load could legally be copied or spilled by hipcc while
-// the load is still in flight.  (Same technique as prefix_attn_w64.hip; tests/test_build_quality.py audits it.)
+// Software pipeline: collect(j) -> issue(j + 1) -> compute(j): one 16 KiB step in flight per wave while the previous one is
+// computed out of registers, 16 KiB of LDS per wave, 8 waves per CU.  Round 4's form double-buffered in LDS (V) and in
+// asm-owned AGPRs (K, loaded straight into operand layout: 16 rows x 64 B per instruction, every quarter wave 16 different
+// cache lines); a timing experiment of this round showed that a coalesced route for K alone is worth 10 % on 8-kv-head shapes
+// (whole-job C5, S = 128: 222 -> 198 us), which is what the landing tiles are for.
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,30 +51,23 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     constexpr int RB = D * 2;        // bytes per K/V row
     constexpr int NCH = D / 32;      // 32-dim chunks of the QK^T contraction
     constexpr int NDB = D / 16;      // 16-wide d blocks of O^T
-    constexpr int RPI = 1024 / RB;   // V rows per DMA instruction
-    constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key V tile
-    constexpr int TILE = 32 * RB;    // bytes of one 32-key V tile (= 16 rows * D floats: reused by the merge)
-    constexpr int NLD = 2 * NCH + NVD;  // vector-memory instructions per step (K fragments + V DMA)
-    // dynamic LDS (8 heads per workgroup are 128 KB): [NWV waves][2 V tiles], then the merge's [NWV][4][16] floats
+    constexpr int RPI = 1024 / RB;   // rows per DMA instruction
+    constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key tile
+    constexpr int TILE = 32 * RB;    // bytes of one 32-key tile (= 16 rows * D floats: reused by the merge)
+    // dynamic LDS: per wave one K and one V landing tile, then the merge's [NWV][4][16] floats
     extern __shared__ __attribute__((aligned(1024))) char gqa_smem[];
-    char(*vtiles)[2][TILE] = reinterpret_cast<char(*)[2][TILE]>(gqa_smem);
+    char(*tiles)[2][TILE] = reinterpret_cast<char(*)[2][TILE]>(gqa_smem);  // [wave][0 = K, 1 = V]
     float(*mlx)[4][16] = reinterpret_cast<float(*)[4][16]>(gqa_smem + NWV * 2 * TILE);
     const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave of the workgroup
     const int wave = WPU == 1 ? 0 : wv;                                                      // wave of the unit
-    char* vtile = vtiles[wv][0];
+    char* ktile = tiles[wv][0];
+    char* vtile = tiles[wv][1];
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g4 = lane >> 4;
-    // workgroup -> (sequence, kv-head group): blockIdx.x runs over B * (Hkv / HPW) pairs in the order the host picked
-    const int ngrp = a.Hkv / HPW;
-    int b, hkg;
-    if (a.gqa_hk_fastest) {
-        b = (int)blockIdx.x / ngrp;
-        hkg = (int)blockIdx.x - b * ngrp;
-    } else {
-        hkg = (int)blockIdx.x / a.B;
-        b = (int)blockIdx.x - hkg * a.B;
-    }
+    // workgroup -> (sequence, kv-head group): blockIdx.x runs over B * (Hkv / HPW) pairs, sequences fastest
+    const int hkg = (int)blockIdx.x / a.B;
+    const int b = (int)blockIdx.x - hkg * a.B;
     const int hk = hkg * HPW + (HPW == 1 ? 0 : wv), row0 = blockIdx.y * 16;
 
     int len = a.kv_len;
@@ -113,20 +104,31 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
                                     has_pre ? (unsigned)a.p_len * v_ts2 : 0u);
     u32x4 krs_c = krs, vrs_c = vrs;  // the segment being walked
     int seg_len = len;
-    // K fragment (A operand): key = l15 of a 16-key block, dims 32 c + 8 g4 .. + 8
-    const unsigned kvoff = (unsigned)l15 * k_ts2 + 16u * g4;
-    // V DMA: instruction i covers tile rows [i * RPI, +RPI); the XOR swizzle of the LDS image is applied to the source chunk
+    // K and V DMA: instruction i covers tile rows [i * RPI, +RPI) -- whole rows, 1 KiB contiguous when the heads of a token are
+    // (Hkv = 1), RPI row pieces of 2 D bytes otherwise; the LDS image of an instruction is lane-linear, so the XOR swizzles of
+    // the two tiles are applied to the per-lane SOURCE chunk (involutions inside a row).
+    //   K tile: 16-byte chunk j of row r sits at position j ^ sw_k(r) -- the A-operand reads below (16 rows, one chunk
+    //           column per quarter wave) then touch every bank once;  sw_k(r) = r & 15 (D = 128), (r >> 1) & 7 (D = 64)
+    //   V tile: 64-byte groups swizzled for the transposing reads (as before)
     const int drow = (lane * 16) / RB, dcp = ((lane * 16) % RB) >> 4;
-    unsigned vvoff[NVD];
+    unsigned kvoff[NVD], vvoff[NVD];
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
         const int r_ = i * RPI + drow;
+        const int swk = D == 128 ? (r_ & 15) : ((r_ >> 1) & 7);
+        kvoff[i] = (unsigned)r_ * k_ts2 + (unsigned)(dcp ^ swk) * 16u;
         const int sw = D == 128 ? (r_ & 3) : ((r_ >> 1) & 1);
         const int vch = (((dcp >> 2) ^ sw) << 2) | (dcp & 3);
         vvoff[i] = (unsigned)r_ * v_ts2 + (unsigned)vch * 16u;
     }
     typedef const __attribute__((address_space(3))) char* lptr_c;
+    const unsigned kt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)ktile);
     const unsigned vt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)vtile);
+    // K fragment (A operand of S^T = K Q^T): key = 16 h + l15, dims 32 c + 8 g4 .. + 8 = chunk 4 c + g4 of the row
+    unsigned kaddr[2];  // byte address of chunk position 0 of this lane's row, key half h; the chunk's position is XORed in per read
+    const int kswz = D == 128 ? l15 : ((l15 >> 1) & 7);  // sw_k of rows l15 and 16 + l15 alike
+#pragma unroll
+    for (int h = 0; h < 2; ++h) kaddr[h] = (unsigned)(uintptr_t)(lptr_c)(ktile + (16 * h + l15) * RB);
     // V^T fragment (A operand of O^T += V^T P^T): d = 16 db + l15, keys {4 g4 + j} (half 0) / {16 + 4 g4 + j} (half 1);
     // the 16-lane group reads the 4 x 16 block, lane l15 supplies row l15 >> 2, columns 4 (l15 & 3) .. + 4
     const int trow = 4 * g4 + (l15 >> 2);
@@ -144,52 +146,78 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
 
     // ---- prefix partials (attention.py:21-43) are dealt to the unit's waves: wave w folds partials w, w + WPU, ... into
     // its own (m, l, O) state -- a normalised partial (O_p, lse_p) IS a state (m = lse_p * log2 e, l = 1, O = O_p) -- and the
-    // merge of the waves then combines everything; no partial is left for the final epilogue.  They ride UNDER the K/V stream:
-    // the wave's k-th partial is requested (into the asm-owned buffer a[64:96]) right after the (k-1)-th was folded and before
-    // step k-1 is computed, i.e. between the loads of key steps k and k+1 -- the counted wait in front of step k covers it,
-    // and it is folded there.  A split prefix level's fp32 slices (C3: 16, C5 slice: 2) thus cost no round trip of their own
-    // as long as the wave has key steps left; what remains is fetched behind the loop, two per round trip.  Not when the
-    // suffix pass's own LSE is asked for (a.lse: the unfused form), which needs the keys-only state at the end.
-    claim_partial_buffer();
+    // merge of the waves then combines everything; no partial is left for the final epilogue.  The wave's FIRST partial (16-bit,
+    // fp32, or a split level's fp32 slice) is requested here, in front of the K/V stream, and folded when the first key step
+    // has landed; the others are fetched behind the loop, two per round trip.  (hipcc counts only its own loads.  A plain load
+    // that is still pending inside the loop makes it insert counted waits that also wait for the next step's DMAs, which it
+    // does not know about -- one plain request before the stream, settled at the first wait, is what stays exact.  Round 5
+    // tried one partial per key step through an asm-owned register buffer: 1 us at the paper default, nothing at C3 / C5.)
+    // Not when the suffix pass's own LSE is asked for (a.lse: the unfused form), which needs the keys-only state at the end.
     const int np = a.n_partials;
-    const bool early = a.lse == nullptr;
-    int kp = 0;             // partials of this wave already folded (its k-th partial is number wave + k * WPU)
-    bool p_flying = false;  // partial kp is in flight to a[64:96]
-    auto request_partial = [&]() __attribute__((always_inline)) {
-        const int i = wave + kp * WPU;
-        if (!early || i >= np) return;
-        const PartialDev& pd = a.partials[i];
-        if (pd.is_f32) {
+    const bool pre = a.lse == nullptr && wave < np;
+    bool pre_folded = !pre;
+    const bool pre_f32 = pre && a.partials[wave].is_f32 != 0;
+    u32x4 pbuf[NDB];  // the first partial's row piece of this lane: dims [16 db + 4 g4, +4) as fp32, or as 16-bit in the low half
+    float plse = -INFINITY;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) pbuf[db] = u32x4{0u, 0u, 0u, 0u};
+    if (pre) {
+        const PartialDev& pd = a.partials[wave];
+        plse = pd.lse[ridx];
+        if (pre_f32) {
             const float* po = static_cast<const float*>(pd.out) + ridx * D + 4 * g4;
-            static_for_g<NDB>([&](auto DB_) { PReg<decltype(DB_)::value>::load_f32(po + 16 * decltype(DB_)::value); });
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) pbuf[db] = *reinterpret_cast<const u32x4*>(po + 16 * db);
         } else {
             const uint16_t* po = static_cast<const uint16_t*>(pd.out) + ridx * D + 4 * g4;
-            static_for_g<NDB>([&](auto DB_) { PReg<decltype(DB_)::value>::load_b16(po + 16 * decltype(DB_)::value); });
-        }
-        preg_load_lse(pd.lse + ridx);
-        p_flying = true;
-    };
-
-    // all vector-memory instructions of one step: K fragments into register set BUF, V tile into LDS tile BUF
-    auto issue = [&](auto BUF_, int key0) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(BUF_)::value;
-        const unsigned ks0 = (unsigned)key0 * k_ts2, ks1 = ks0 + 16u * k_ts2, vsoff = (unsigned)key0 * v_ts2;
-        static_for_g<NCH>([&](auto C_) {
-            constexpr int c = decltype(C_)::value;
-            KReg<BUF * 8 + c>::template load<64 * c, NT>(krs_c, kvoff, ks0);
-            KReg<BUF * 8 + 4 + c>::template load<64 * c, NT>(krs_c, kvoff, ks1);
-        });
 #pragma unroll
-        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs_c, vvoff[i], vsoff, vt0 + BUF * TILE + i * 1024);
+            for (int db = 0; db < NDB; ++db) {
+                const u32x2 u = *reinterpret_cast<const u32x2*>(po + 16 * db);
+                pbuf[db][0] = u[0];
+                pbuf[db][1] = u[1];
+            }
+        }
+    }
+
+    // ---- one 32-key step --------------------------------------------------------------------------------------------------
+    // issue:   2 NVD LDS-DMA instructions, K rows -> K tile, V rows -> V tile (zero fill past the segment's end)
+    // collect: the landed tiles -> registers (K: 2 NCH ds_read_b128 in the A-operand layout; V^T: 2 NDB transposing reads), after
+    //          which both tiles are free for the next step's DMA
+    // compute: S^T = K Q^T, online softmax, O^T += V^T P^T, all from registers
+    // The loop keeps ONE step in flight per wave while the previous one is computed (collect(j); issue(j + 1); compute(j)):
+    // 16 KiB per wave, 8 waves per CU.  (Round 4's form loaded K straight into MFMA operand layout -- 16 rows x 64 B per
+    // instruction, every quarter wave 16 different cache lines -- and ran 10 % below this one on 8-kv-head shapes.)
+    u32x4 kf[2][NCH];
+    u32x4 vf[NDB];
+    auto issue = [&](int key0) __attribute__((always_inline)) {
+        const unsigned ksoff = (unsigned)key0 * k_ts2, vsoff = (unsigned)key0 * v_ts2;
+#pragma unroll
+        for (int i = 0; i < NVD; ++i) dma16_g<NT>(krs_c, kvoff[i], ksoff, kt0 + i * 1024);
+#pragma unroll
+        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs_c, vvoff[i], vsoff, vt0 + i * 1024);
     };
-    auto step = [&](auto BUF_, int key0) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(BUF_)::value;
-        f32x4 s0, s1;
-        static_for_g<NCH>([&](auto C_) {
-            constexpr int c = decltype(C_)::value;
-            KReg<BUF * 8 + c>::template qk<T, c == 0>(s0, qf[c]);
-            KReg<BUF * 8 + 4 + c>::template qk<T, c == 0>(s1, qf[c]);
-        });
+    auto collect = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                kf[h][c] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(kaddr[h] + (unsigned)(((4 * c + g4) ^ kswz) << 4)));
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const u32x2 t0 = lds_tr16_g(vaddr[db]);
+            const u32x2 t1 = lds_tr16_g(vaddr[db] + 16 * RB);
+            vf[db] = u32x4{t0[0], t0[1], t1[0], t1[1]};
+        }
+        // every read has returned before the tiles are handed to the next DMA (asm: hipcc does not order it against them otherwise)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto compute = [&](int key0) __attribute__((always_inline)) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            mfma16_acc<T>(s0, kf[0][c], qf[c]);
+            mfma16_acc<T>(s1, kf[1][c], qf[c]);
+        }
         // the MFMAs above are asm: hipcc's hazard recogniser does not see that their results need the pipeline drained
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s0), "+v"(s1));
         // scores of this lane: keys key0 + 4 g4 + i (s0) and key0 + 16 + 4 g4 + i (s1), query row l15
@@ -216,16 +244,13 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         const u32x4 pf = {TR::pack2(p[0], p[1]), TR::pack2(p[2], p[3]), TR::pack2(p[4], p[5]), TR::pack2(p[6], p[7])};
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-            const u32x2 t0 = lds_tr16_g(vaddr[db] + BUF * TILE);
-            const u32x2 t1 = lds_tr16_g(vaddr[db] + BUF * TILE + 16 * RB);
-            const u32x4 vf = {t0[0], t0[1], t1[0], t1[1]};
             o[db] *= alpha;
-            mfma16_acc<T>(o[db], vf, pf);
+            mfma16_acc<T>(o[db], vf[db], pf);
         }
-        // tile BUF is overwritten by the DMA of step i+2: every transposing read above has returned; and the accumulators
-        // are read by plain VALU code next (the rescale of the next step, the epilogue): drain the matrix pipeline
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        // the accumulators are read by plain VALU code next (the rescale of the next step, a fold, the epilogue): drain the matrix pipeline
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     };
+
     // ---- folding a prefix partial into this wave's state -----------------------------------------------------------------
     auto fold = [&](float lse_p, const f32x4(&x)[NDB]) __attribute__((always_inline)) {
         const float m_p = lse_p * 1.4426950408889634f;
@@ -254,76 +279,49 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
             widen(u, x);
         }
     };
-    // the partial in a[64:96] has landed (the caller waited): read it back, fold it
-    auto take_partial = [&]() __attribute__((always_inline)) {
-        const bool f32 = a.partials[wave + kp * WPU].is_f32 != 0;
+    // the first partial has landed (the caller waited for every outstanding load): fold it
+    auto fold_pre = [&]() __attribute__((always_inline)) {
         f32x4 x[NDB];
-        static_for_g<NDB>([&](auto DB_) {
-            constexpr int db = decltype(DB_)::value;
-            const unsigned w0 = PReg<db>::template read<0>(), w1 = PReg<db>::template read<1>();
-            if (f32) {
-                const unsigned w2 = PReg<db>::template read<2>(), w3 = PReg<db>::template read<3>();
-                x[db] = f32x4{__builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1), __builtin_bit_cast(float, w2), __builtin_bit_cast(float, w3)};
-            } else {
-                x[db] = f32x4{TR::lo(w0), TR::hi(w0), TR::lo(w1), TR::hi(w1)};
-            }
-        });
-        fold(preg_read_lse(), x);
-        ++kp;
-        p_flying = false;
+        // opaque: hipcc must not hoist the conversions below (and with them its wait for the request) in front of the stream
+        asm volatile("" : "+v"(plse));
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) asm volatile("" : "+v"(pbuf[db]));
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const f32x4 xf = __builtin_bit_cast(f32x4, pbuf[db]);
+            const f32x4 xh = f32x4{TR::lo(pbuf[db][0]), TR::hi(pbuf[db][0]), TR::lo(pbuf[db][1]), TR::hi(pbuf[db][1])};
+            x[db] = pre_f32 ? xf : xh;
+        }
+        fold(plse, x);
+        pre_folded = true;
     };
-    for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline (its last wait is vmcnt(0))
-        using std::integral_constant;
+    for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline
         if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_len = a.p_len; }
         else { krs_c = krs; vrs_c = vrs; seg_len = len; }
         constexpr int stride = 32 * WPU;
         const int k_first = wave * 32;
         const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
-        auto key_of = [&](int j) { return k_first + j * stride; };
         if (nst > 0) {
-            issue(integral_constant<int, 0>{}, key_of(0));
-            if (!p_flying) request_partial();  // younger than step 0's loads, older than step 1's
-            for (int j = 0;;) {
-                bool more = j + 1 < nst;
-                if (more) {
-                    issue(integral_constant<int, 1>{}, key_of(j + 1));
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");  // step j (and the partial behind it) landed, step j+1 in flight
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (p_flying) {
-                    take_partial();
-                    request_partial();
-                }
-                step(integral_constant<int, 0>{}, key_of(j));
-                if (!more) break;
-                ++j;
-                more = j + 1 < nst;
-                if (more) {
-                    issue(integral_constant<int, 0>{}, key_of(j + 1));
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NLD) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (p_flying) {
-                    take_partial();
-                    request_partial();
-                }
-                step(integral_constant<int, 1>{}, key_of(j));
-                if (!more) break;
-                ++j;
+            issue(k_first);
+            for (int j = 0; j < nst; ++j) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step j's tiles have landed (and, the first time, q and the first partial)
+                // hipcc counts only its own loads (q, the first partial): make it settle them HERE, where nothing is in flight -- a
+                // counted wait of its own further down would also wait for the next step's DMAs, which it does not know about
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) asm volatile("" ::"v"(qf[c]));
+                if (!pre_folded) fold_pre();
+                collect();
+                if (j + 1 < nst) issue(k_first + (j + 1) * stride);  // in flight while step j is computed
+                compute(k_first + j * stride);
             }
         }
     }
     // the keys-only state (the LSE output is the suffix pass's own; when it is asked for, no partial was folded above)
     const float m_s = m_run, l_s = l_run;
-    if (p_flying) {  // requested in front of the last step: landed under its arithmetic
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        take_partial();
-    }
+    if (!pre_folded) fold_pre();  // a wave without a key step (hipcc's own wait covers the request)
 
-    // ---- this wave's partials that found no key step to ride under ----------------------------------------------------
-    for (int i = wave + kp * WPU; i < np; i += 2 * WPU) {
+    // ---- this wave's other partials (all of them when the LSE output is asked for) ---------------------------------------
+    for (int i = wave + (pre ? WPU : 0); i < np; i += 2 * WPU) {
         // two partials per round trip: their lse values and 2 * D/16 row pieces are all requested before the first use
         const bool two = i + WPU < np;
         const int i1 = two ? i + WPU : i;
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         fold(lse1, x1);
     }
 
-    // ---- merge the WPU waves of the unit: every wave leaves (m, l, O^T) in its own tile, wave 0 folds them -------
+    // ---- merge the WPU waves of the unit: every wave leaves (m, l, O^T) in its own V tile, wave 0 folds them -------
     float ms_run = m_s, ls_run = l_s;
     if constexpr (WPU > 1) {
         float* mine = reinterpret_cast<float*>(vtile);  // [16 rows][D]: O (unnormalised)
@@ -354,7 +352,7 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         if (wave != 0) return;
 #pragma unroll
         for (int w = 1; w < WPU; ++w) {
-            const float* oth = reinterpret_cast<const float*>(vtiles[w][0]);
+            const float* oth = reinterpret_cast<const float*>(tiles[w][1]);
             const float m2 = mlx[w][0][l15], l2 = mlx[w][1][l15];
             const float mf = fmaxf(m_run, m2);
             const float ms = (mf == -INFINITY) ? 0.f : mf;
@@ -420,7 +418,6 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
     if (const char* e = getenv("HYD_GQA_HPW")) hpw = few_units ? 1 : atoi(e);
-    if (const char* e = getenv("HYD_GQA_ORDER")) a.gqa_hk_fastest = atoi(e);
 #endif
     dim3 grid((unsigned)a.B * (unsigned)(a.Hkv / hpw), chunks, 1);
     size_t pad = 0;  // development: dynamic LDS that only lowers the occupancy (waves per CU = 160 KiB / (16 KiB + pad))
