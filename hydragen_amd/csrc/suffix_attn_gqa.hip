@@ -146,35 +146,41 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
 
     // ---- prefix partials (attention.py:21-43) are dealt to the unit's waves: wave w folds partials w, w + WPU, ... into
     // its own (m, l, O) state -- a normalised partial (O_p, lse_p) IS a state (m = lse_p * log2 e, l = 1, O = O_p) -- and the
-    // merge of the waves then combines everything; no partial is left for the final epilogue.  The wave's FIRST partial (16-bit,
-    // fp32, or a split level's fp32 slice) is requested here, in front of the K/V stream, and folded when the first key step
+    // merge of the waves then combines everything; no partial is left for the final epilogue.  The wave's first TWO partials (16-bit,
+    // fp32, or a split level's fp32 slices) are requested here, in front of the K/V stream, and folded when the first key step
     // has landed; the others are fetched behind the loop, two per round trip.  (hipcc counts only its own loads.  A plain load
     // that is still pending inside the loop makes it insert counted waits that also wait for the next step's DMAs, which it
     // does not know about -- one plain request before the stream, settled at the first wait, is what stays exact.  Round 5
     // tried one partial per key step through an asm-owned register buffer: 1 us at the paper default, nothing at C3 / C5.)
     // Not when the suffix pass's own LSE is asked for (a.lse: the unfused form), which needs the keys-only state at the end.
     const int np = a.n_partials;
-    const bool pre = a.lse == nullptr && wave < np;
-    bool pre_folded = !pre;
-    const bool pre_f32 = pre && a.partials[wave].is_f32 != 0;
-    u32x4 pbuf[NDB];  // the first partial's row piece of this lane: dims [16 db + 4 g4, +4) as fp32, or as 16-bit in the low half
-    float plse = -INFINITY;
+    constexpr int NPRE = 2;  // partials of this wave requested in front of the stream (a split level's two slices at C5; 2 of 4 at C3)
+    const int npre = a.lse != nullptr ? 0 : min(NPRE, (np - wave + WPU - 1) / WPU);  // (np <= wave: 0)
+    bool pre_folded = npre <= 0;
+    bool pre_f32[NPRE];
+    u32x4 pbuf[NPRE][NDB];  // a partial's row piece of this lane: dims [16 db + 4 g4, +4) as fp32, or as 16-bit in the low half
+    float plse[NPRE];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) pbuf[db] = u32x4{0u, 0u, 0u, 0u};
-    if (pre) {
-        const PartialDev& pd = a.partials[wave];
-        plse = pd.lse[ridx];
-        if (pre_f32) {
-            const float* po = static_cast<const float*>(pd.out) + ridx * D + 4 * g4;
+    for (int k = 0; k < NPRE; ++k) {
+        pre_f32[k] = false;
+        plse[k] = -INFINITY;
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) pbuf[db] = *reinterpret_cast<const u32x4*>(po + 16 * db);
-        } else {
-            const uint16_t* po = static_cast<const uint16_t*>(pd.out) + ridx * D + 4 * g4;
+        for (int db = 0; db < NDB; ++db) pbuf[k][db] = u32x4{0u, 0u, 0u, 0u};
+        if (k < npre) {
+            const PartialDev& pd = a.partials[wave + k * WPU];
+            pre_f32[k] = pd.is_f32 != 0;
+            plse[k] = pd.lse[ridx];
+            if (pre_f32[k]) {
+                const float* po = static_cast<const float*>(pd.out) + ridx * D + 4 * g4;
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) {
-                const u32x2 u = *reinterpret_cast<const u32x2*>(po + 16 * db);
-                pbuf[db][0] = u[0];
-                pbuf[db][1] = u[1];
+                for (int db = 0; db < NDB; ++db) pbuf[k][db] = *reinterpret_cast<const u32x4*>(po + 16 * db);
+            } else {
+                const uint16_t* po = static_cast<const uint16_t*>(pd.out) + ridx * D + 4 * g4;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {  // (upper half undefined: no move, hence no wait, between the load and its register)
+                    const u32x2 u = *reinterpret_cast<const u32x2*>(po + 16 * db);
+                    pbuf[k][db] = __builtin_shufflevector(u, u, 0, 1, -1, -1);
+                }
             }
         }
     }
@@ -279,20 +285,25 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
             widen(u, x);
         }
     };
-    // the first partial has landed (the caller waited for every outstanding load): fold it
+    // the pre-requested partials have landed (the caller waited for every outstanding load): fold them
     auto fold_pre = [&]() __attribute__((always_inline)) {
-        f32x4 x[NDB];
-        // opaque: hipcc must not hoist the conversions below (and with them its wait for the request) in front of the stream
-        asm volatile("" : "+v"(plse));
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) asm volatile("" : "+v"(pbuf[db]));
+        for (int k = 0; k < NPRE; ++k) {
+            // opaque: hipcc must not hoist the conversions below (and with them its wait for the request) in front of the stream
+            asm volatile("" : "+v"(plse[k]));
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            const f32x4 xf = __builtin_bit_cast(f32x4, pbuf[db]);
-            const f32x4 xh = f32x4{TR::lo(pbuf[db][0]), TR::hi(pbuf[db][0]), TR::lo(pbuf[db][1]), TR::hi(pbuf[db][1])};
-            x[db] = pre_f32 ? xf : xh;
+            for (int db = 0; db < NDB; ++db) asm volatile("" : "+v"(pbuf[k][db]));
+            if (k < npre) {
+                f32x4 x[NDB];
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const f32x4 xf = __builtin_bit_cast(f32x4, pbuf[k][db]);
+                    const f32x4 xh = f32x4{TR::lo(pbuf[k][db][0]), TR::hi(pbuf[k][db][0]), TR::lo(pbuf[k][db][1]), TR::hi(pbuf[k][db][1])};
+                    x[db] = pre_f32[k] ? xf : xh;
+                }
+                fold(plse[k], x);
+            }
         }
-        fold(plse, x);
         pre_folded = true;
     };
     for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     if (!pre_folded) fold_pre();  // a wave without a key step (hipcc's own wait covers the request)
 
     // ---- this wave's other partials (all of them when the LSE output is asked for) ---------------------------------------
-    for (int i = wave + (pre ? WPU : 0); i < np; i += 2 * WPU) {
+    for (int i = wave + max(npre, 0) * WPU; i < np; i += 2 * WPU) {
         // two partials per round trip: their lse values and 2 * D/16 row pieces are all requested before the first use
         const bool two = i + WPU < np;
         const int i1 = two ? i + WPU : i;

@@ -143,6 +143,9 @@ def test_gqa_suffix_kernel_names_no_register_by_hand():
         body = m.group(2)
         first_dma = body.find(" lds")
         assert first_dma > 0, m.group(1)
+        # ... and none between the request of q / the first partials and the first DMA (they ride under the stream)
+        q_load = body.find("global_load_dwordx4")
+        assert 0 < q_load < first_dma and "vmcnt" not in body[q_load:first_dma], (m.group(1), "hipcc waits for q or a partial in front of the K/V stream")
         lines = body[first_dma:].splitlines()
         last_dma = max(i for i, ln in enumerate(lines) if ln.rstrip().endswith(" lds") or " lds " in ln)
         counted = [ln.strip() for ln in lines[:last_dma] if re.search(r"s_waitcnt vmcnt\((?!0\))", ln)]
