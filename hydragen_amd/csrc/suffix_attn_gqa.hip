@@ -40,7 +40,7 @@ namespace hyd {
 // token's [Hkv, D] row are requested together -- whole DRAM pages instead of one eighth of a page per visit (the one-wave
 // workgroups of a sequence's heads are 2048 workgroups apart in dispatch order).  No wave talks to another.
 template <typename T, int D, int WPU, bool NT, int HPW = 1>
-__global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(2, 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
+__global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : 2, D == 256 ? 1 : 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
     static_assert(WPU == 1 || HPW == 1, "several heads per workgroup: one-wave units only");
     constexpr int NWV = WPU * HPW;  // waves per workgroup
     // every field a wave needs (and partials[0]) sits in the first 256 bytes of SuffixArgs: one scalar-cache miss at the start of
@@ -108,16 +108,16 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     // (Hkv = 1), RPI row pieces of 2 D bytes otherwise; the LDS image of an instruction is lane-linear, so the XOR swizzles of
     // the two tiles are applied to the per-lane SOURCE chunk (involutions inside a row).
     //   K tile: 16-byte chunk j of row r sits at position j ^ sw_k(r) -- the A-operand reads below (16 rows, one chunk
-    //           column per quarter wave) then touch every bank once;  sw_k(r) = r & 15 (D = 128), (r >> 1) & 7 (D = 64)
+    //           column per quarter wave) then touch every bank once;  sw_k(r) = r & 15 (D >= 128), (r >> 1) & 7 (D = 64)
     //   V tile: 64-byte groups swizzled for the transposing reads (as before)
     const int drow = (lane * 16) / RB, dcp = ((lane * 16) % RB) >> 4;
     unsigned kvoff[NVD], vvoff[NVD];
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
         const int r_ = i * RPI + drow;
-        const int swk = D == 128 ? (r_ & 15) : ((r_ >> 1) & 7);
+        const int swk = D >= 128 ? (r_ & 15) : ((r_ >> 1) & 7);
         kvoff[i] = (unsigned)r_ * k_ts2 + (unsigned)(dcp ^ swk) * 16u;
-        const int sw = D == 128 ? (r_ & 3) : ((r_ >> 1) & 1);
+        const int sw = D >= 128 ? (r_ & 3) : ((r_ >> 1) & 1);
         const int vch = (((dcp >> 2) ^ sw) << 2) | (dcp & 3);
         vvoff[i] = (unsigned)r_ * v_ts2 + (unsigned)vch * 16u;
     }
@@ -126,13 +126,13 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     const unsigned vt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)vtile);
     // K fragment (A operand of S^T = K Q^T): key = 16 h + l15, dims 32 c + 8 g4 .. + 8 = chunk 4 c + g4 of the row
     unsigned kaddr[2];  // byte address of chunk position 0 of this lane's row, key half h; the chunk's position is XORed in per read
-    const int kswz = D == 128 ? l15 : ((l15 >> 1) & 7);  // sw_k of rows l15 and 16 + l15 alike
+    const int kswz = D >= 128 ? l15 : ((l15 >> 1) & 7);  // sw_k of rows l15 and 16 + l15 alike
 #pragma unroll
     for (int h = 0; h < 2; ++h) kaddr[h] = (unsigned)(uintptr_t)(lptr_c)(ktile + (16 * h + l15) * RB);
     // V^T fragment (A operand of O^T += V^T P^T): d = 16 db + l15, keys {4 g4 + j} (half 0) / {16 + 4 g4 + j} (half 1);
     // the 16-lane group reads the 4 x 16 block, lane l15 supplies row l15 >> 2, columns 4 (l15 & 3) .. + 4
     const int trow = 4 * g4 + (l15 >> 2);
-    const int tsw = D == 128 ? (trow & 3) : ((trow >> 1) & 1);
+    const int tsw = D >= 128 ? (trow & 3) : ((trow >> 1) & 1);
     unsigned vaddr[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     // tried one partial per key step through an asm-owned register buffer: 1 us at the paper default, nothing at C3 / C5.)
     // Not when the suffix pass's own LSE is asked for (a.lse: the unfused form), which needs the keys-only state at the end.
     const int np = a.n_partials;
-    constexpr int NPRE = 2;  // partials of this wave requested in front of the stream (a split level's two slices at C5; 2 of 4 at C3)
+    constexpr int NPRE = D == 256 ? 1 : 2;  // partials of this wave requested in front of the stream (a split level's two slices at C5; 2 of 4 at C3)
     const int npre = a.lse != nullptr ? 0 : min(NPRE, (np - wave + WPU - 1) / WPU);  // (np <= wave: 0)
     bool pre_folded = npre <= 0;
     bool pre_f32[NPRE];
@@ -393,14 +393,23 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// shapes only: fewer than 4 one-wave units per CU (measured: B=32, 8/1 heads, 1152 keys 48 -> 31 us; at 1024 and
+// 2048 units -- C3, C5 -- one wave per unit is as fast or faster), and enough keys to deal out
+static bool gqa_few_units(const SuffixArgs& a, int chunks) {
+    return (int64_t)a.units * chunks < 256 * 4 && a.kv_len + (a.pk ? a.p_len : 0) >= 128;
+}
+
 // Shapes-only eligibility (capture-safe): enough query rows per unit for the matrix cores to pay, enough units to
 // fill the chip with one wave each, and byte offsets inside a unit's cache that fit the 32-bit buffer addressing.
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
-    if (D != 64 && D != 128) return false;
+    if (D != 64 && D != 128 && D != 256) return false;
     const int64_t chunks = (a.rows + 15) / 16;
     // measured on MI355X: 4 rows per unit is where the matrix cores win (g = 2 is still faster on the VALU kernel), at
     // every unit count from 4 to 8192 (tools/kbench.py, HYD_SUFFIX_IMPL=valu|gqa)
     if (!any_shape && a.rows < 4) return false;
+    // head dim 256 (32 KB of tiles and one SIMD per wave): measured against the dot-product kernel, 7 x faster with one wave per
+    // unit (B = 2048, 8/1 heads, S = 256: 667 -> 90 us) but 15 % slower in the four-waves-per-unit form that few units take
+    if (D == 256 && gqa_few_units(a, (int)chunks)) return false;
     const int64_t span = (int64_t)a.kv_len * (a.k_ts > a.v_ts ? a.k_ts : a.v_ts) * 2;
     return span < (int64_t)1 << 31 && a.Hkv <= 65535 && chunks <= 65535;
 }
@@ -421,11 +430,9 @@ template <typename T, int D>
 static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
     SuffixArgs a = a_in;
     const int chunks = (a.rows + 15) / 16;
-    // shapes only: fewer than 4 one-wave units per CU (measured: B=32, 8/1 heads, 1152 keys 48 -> 31 us; at 1024 and
-    // 2048 units -- C3, C5 -- one wave per unit is as fast or faster), and enough keys to deal out
-    bool few_units = (int64_t)a.units * chunks < 256 * 4 && a.kv_len + (a.pk ? a.p_len : 0) >= 128;
+    bool few_units = gqa_few_units(a, chunks);
     int hpw = 1;  // kv heads of a sequence per workgroup: one-wave units of the unique phase with several kv heads
-    if (!few_units && !a.shared_kv && !a.pk) hpw = a.Hkv % 8 == 0 ? 8 : a.Hkv % 4 == 0 ? 4 : a.Hkv % 2 == 0 ? 2 : 1;
+    if (!few_units && !a.shared_kv && !a.pk) hpw = (a.Hkv % 8 == 0 && D < 256) ? 8 : a.Hkv % 4 == 0 ? 4 : a.Hkv % 2 == 0 ? 2 : 1;  // (D = 256: 32 KB of tiles per wave)
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
     if (const char* e = getenv("HYD_GQA_HPW")) hpw = few_units ? 1 : atoi(e);
@@ -435,13 +442,19 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_LDS_PAD")) pad = (size_t)atoi(e);
 #endif
-    if (a.shared_kv) {  // a small shared level: its keys are read by several workgroups, default cache policy
-        if (few_units) return launch_gqa_k<T, D, 4, false, 1>(a, grid, 0, s);
-        return launch_gqa_k<T, D, 1, false, 1>(a, grid, pad, s);
+    if constexpr (D == 256) {
+        if (few_units || a.shared_kv) return (int)hipErrorInvalidValue;  // (not eligible: suffix_gqa_eligible, level_is_small)
+    } else {
+        if (a.shared_kv) {  // a small shared level: its keys are read by several workgroups, default cache policy
+            if (few_units) return launch_gqa_k<T, D, 4, false, 1>(a, grid, 0, s);
+            return launch_gqa_k<T, D, 1, false, 1>(a, grid, pad, s);
+        }
+        if (few_units) return launch_gqa_k<T, D, 4, true, 1>(a, grid, 0, s);
     }
-    if (few_units) return launch_gqa_k<T, D, 4, true, 1>(a, grid, 0, s);
     switch (hpw) {
-        case 8: return launch_gqa_k<T, D, 1, true, 8>(a, grid, 0, s);
+        case 8:
+            if constexpr (D < 256) return launch_gqa_k<T, D, 1, true, 8>(a, grid, 0, s);
+            else return (int)hipErrorInvalidValue;
         case 4: return launch_gqa_k<T, D, 1, true, 4>(a, grid, 0, s);
         case 2: return launch_gqa_k<T, D, 1, true, 2>(a, grid, 0, s);
         default: return launch_gqa_k<T, D, 1, true, 1>(a, grid, pad, s);
@@ -452,9 +465,11 @@ int launch_suffix_gqa(const SuffixArgs& a, int dtype, int D, hipStream_t s) {
     if (dtype == HYD_F16) {
         if (D == 128) return launch_gqa_t<F16, 128>(a, s);
         if (D == 64) return launch_gqa_t<F16, 64>(a, s);
+        if (D == 256) return launch_gqa_t<F16, 256>(a, s);
     } else {
         if (D == 128) return launch_gqa_t<BF16, 128>(a, s);
         if (D == 64) return launch_gqa_t<BF16, 64>(a, s);
+        if (D == 256) return launch_gqa_t<BF16, 256>(a, s);
     }
     return (int)hipErrorInvalidValue;
 }

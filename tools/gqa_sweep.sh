@@ -1,8 +1,11 @@
-# development: A/B of two builds of the library on the grouped-query shapes (base = build_probe/libhydragen_base.so)
+# development: head dim 256 on the two suffix kernels (ablation library)
+export HYDRAGEN_HIP_LIB=build_probe/libhydragen_abl.so
 for rep in 1 2; do
- for lib in build_probe/libhydragen_base.so hydragen_amd/csrc/libhydragen_hip.so; do
-   echo "rep=$rep $(basename $lib)"
-   HYDRAGEN_HIP_LIB=$lib timeout 600 python tools/phase_bench.py --only "C" 2>&1 | grep "^| C[35]"
-   HYDRAGEN_HIP_LIB=$lib timeout 600 python tools/phase_bench.py --only "paper" 2>&1 | grep "^| paper"
+ for impl in valu gqa; do
+   for shape in "8 1 2048" "32 8 64" "16 2 1024"; do
+   set -- $shape
+   r=$(HYD_SUFFIX_IMPL=$impl timeout 300 python tools/kbench.py fused --D 256 --B $3 --Hq $1 --Hkv $2 --S 16,64,128,256 --iters 20 2>&1 | grep fused | sed -E 's/.*S= *([0-9]+) +([0-9.]+) us.*/\1:\2/' | tr '\n' ' ')
+   echo "rep=$rep $impl D=256 B=$3 heads=$1/$2  $r"
+   done
  done
 done
