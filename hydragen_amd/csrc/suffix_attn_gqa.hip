@@ -36,9 +36,9 @@ namespace hyd {
 // units on 256 CUs, C5: 2048), where nothing but more waves hides the per-step load latency.
 // NT: K/V loads carry the non-temporal hint (suffix_gqa_common.h): the unique phase, where every key is read once.
 // HPW: kv heads per workgroup (WPU = 1 only).  The HPW one-wave units of a workgroup are the kv heads hk0 .. hk0 + HPW - 1 of ONE
-// sequence: they start together, have the same length and walk the same tokens, so the 256-byte pieces they read of every
-// token's [Hkv, D] row are requested together -- whole DRAM pages instead of one eighth of a page per visit (the one-wave
-// workgroups of a sequence's heads are 2048 workgroups apart in dispatch order).  No wave talks to another.
+// sequence: they start together, have the same length and walk the same tokens, so the 2 D-byte pieces they read of every
+// token's [Hkv, D] row are requested together (the one-wave workgroups of a sequence's heads are B workgroups apart in
+// dispatch order).  No wave talks to another.  Chosen from shapes in launch_gqa_t (measurements there).
 template <typename T, int D, int WPU, bool NT, int HPW = 1>
 __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : 2, D == 256 ? 1 : 2))) void suffix_attn_gqa_kernel(const SuffixArgs a) {
     static_assert(WPU == 1 || HPW == 1, "several heads per workgroup: one-wave units only");
@@ -404,9 +404,10 @@ static bool gqa_few_units(const SuffixArgs& a, int chunks) {
 bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
     if (D != 64 && D != 128 && D != 256) return false;
     const int64_t chunks = (a.rows + 15) / 16;
-    // measured on MI355X: 4 rows per unit is where the matrix cores win (g = 2 is still faster on the VALU kernel), at
-    // every unit count from 4 to 8192 (tools/kbench.py, HYD_SUFFIX_IMPL=valu|gqa)
-    if (!any_shape && a.rows < 4) return false;
+    // measured on MI355X (tools/kbench.py, HYD_SUFFIX_IMPL=valu|gqa; round 5's kernel): from 3 rows per unit the matrix cores win at
+    // every suffix length (12/4 heads, B = 1024: 10.2 / 23.4 / 82.5 us at S = 8 / 64 / 256 against 12.0 / 30.6 / 104); with 2 rows they win
+    // from S = 64 on and lose below (16/8 heads: 20 vs 14 us at S = 8), with 1 row only from S = 128: those stay on the dot-product kernel
+    if (!any_shape && a.rows < 3) return false;
     // head dim 256 (32 KB of tiles and one SIMD per wave): measured against the dot-product kernel, 7 x faster with one wave per
     // unit (B = 2048, 8/1 heads, S = 256: 667 -> 90 us) but 15 % slower in the four-waves-per-unit form that few units take
     if (D == 256 && gqa_few_units(a, (int)chunks)) return false;
@@ -431,8 +432,16 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
     SuffixArgs a = a_in;
     const int chunks = (a.rows + 15) / 16;
     bool few_units = gqa_few_units(a, chunks);
-    int hpw = 1;  // kv heads of a sequence per workgroup: one-wave units of the unique phase with several kv heads
-    if (!few_units && !a.shared_kv && !a.pk) hpw = (a.Hkv % 8 == 0 && D < 256) ? 8 : a.Hkv % 4 == 0 ? 4 : a.Hkv % 2 == 0 ? 2 : 1;  // (D = 256: 32 KB of tiles per wave)
+    // kv heads of a sequence per workgroup (one-wave units of the unique phase).  Measured with this kernel (profiles/r05_gqa_hpw.txt,
+    // us at S = 32 / 128 / 256): 8 kv heads: 1 head per workgroup 61 / 197 / 364, 2: 60 / 185 / 355, 4: 64 / 184 / 352, 8: 71 / 187 / 341 -- a
+    // workgroup that fills the CU's LDS alone (8 x 16 KB) leaves it idle between workgroups, which short suffixes pay for; 16 kv heads:
+    // 1: 55 / 181 / 348, 4: 63 / 211 / 403, 8: 70 / 223 / 446 -- a part of a token's row per workgroup is worse than one head.  So: all
+    // heads of the token in one workgroup when there are at most 4 (<= 64 KB of tiles: two workgroups per CU), 4 of 8, else one.
+    int hpw = 1;
+    if (!few_units && !a.shared_kv && !a.pk && a.Hkv <= 8) {
+        hpw = a.Hkv % 4 == 0 ? 4 : a.Hkv % 2 == 0 ? 2 : 1;
+        if (D == 256 && hpw > 2) hpw = 2;  // 32 KB of tiles per wave
+    }
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
     if (const char* e = getenv("HYD_GQA_HPW")) hpw = few_units ? 1 : atoi(e);
@@ -452,10 +461,14 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
         if (few_units) return launch_gqa_k<T, D, 4, true, 1>(a, grid, 0, s);
     }
     switch (hpw) {
-        case 8:
+#ifdef HYD_ABLATION_BUILD
+        case 8:  // (A/B only: not chosen from shapes any more)
             if constexpr (D < 256) return launch_gqa_k<T, D, 1, true, 8>(a, grid, 0, s);
             else return (int)hipErrorInvalidValue;
-        case 4: return launch_gqa_k<T, D, 1, true, 4>(a, grid, 0, s);
+#endif
+        case 4:
+            if constexpr (D < 256) return launch_gqa_k<T, D, 1, true, 4>(a, grid, 0, s);
+            else return (int)hipErrorInvalidValue;
         case 2: return launch_gqa_k<T, D, 1, true, 2>(a, grid, 0, s);
         default: return launch_gqa_k<T, D, 1, true, 1>(a, grid, pad, s);
     }

@@ -88,13 +88,17 @@ def test_flash_attention_varlen(dt):
     (2, 3, 40, 4, 2, [40, 17]),          # several queries per sequence (nq*g = 6 rows)
     (2, 5, 33, 8, 2, [33, 2]),           # nq*g = 20 rows -> row chunks
     (5, 1, 8, 4, 4, [0, 8, 1, 0, 3]),    # empty sequences
+    (3, 1, 70, 12, 4, [70, 1, 33]),      # g = 3: the smallest row count on the matrix-core kernel
+    (300, 1, 40, 6, 2, None),            # g = 3, many units: one wave per unit, 2 kv heads per workgroup
+    (300, 1, 40, 40, 8, None),           # g = 5, 8 kv heads: 4 of them per workgroup
+    (260, 1, 40, 64, 16, None),          # 16 kv heads: one per workgroup
 ])
 def test_flash_attention_seqlen(dt, D, b, nq, mk, hq, hkv, lens):
     from hydragen_amd.flash import flash_attention_seqlen
 
     rng = np.random.default_rng(zlib.crc32(repr((dt, D, b, nq, mk)).encode()))
     q, k, v = _rand(rng, (b, nq, hq, D), dt), _rand(rng, (b, mk, hkv, D), dt), _rand(rng, (b, mk, hkv, D), dt)
-    sl = np.asarray(lens, dtype=np.int32)
+    sl = np.asarray(lens, dtype=np.int32) if lens is not None else rng.integers(0, mk + 1, b).astype(np.int32)
     out, lse = flash_attention_seqlen(dev(q, dt), dev(k, dt), dev(v, dt), seq_len=dev(sl))
     torch.cuda.synchronize()
     want, wlse = O.flash_attention_seqlen(q, k, v, sl)
