@@ -23,6 +23,7 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--splits", type=int, default=0, help="0 = the library's own split-KV plan")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--slices", type=int, default=0, help="fused: hand the suffix pass N stacked fp32 slices (a split prefix level) instead of one 16-bit partial")
+ap.add_argument("--partials", type=int, default=1, help="fused: number of separate 16-bit partials (shared levels) handed to the suffix pass")
 ap.add_argument("--kv-gap", type=int, default=0, help="suffix: bytes between the end of K and the start of V in their arena (-1: two allocations)")
 ap.add_argument("--smax", type=int, default=0, help="suffix: token rows of the cache allocation (default: the largest --S)")
 ap.add_argument("--pad-tokens", type=int, default=0, help="suffix: extra token rows per sequence in the cache allocation (batch stride (S + pad) rows)")
@@ -84,7 +85,11 @@ else:
                 sl_o = torch.randn(a.slices * al_(rows_ * a.D * 4) // 4, device=dev, dtype=torch.float32); sl_l = torch.randn(a.slices * al_(rows_ * 4) // 4, device=dev, dtype=torch.float32)
             sp.n_partials = 1; sp.partials[0].out = sl_o.data_ptr(); sp.partials[0].lse = sl_l.data_ptr(); sp.partials[0].count = a.slices; sp.partials[0].is_f32 = 1
         elif a.what == "fused":
-            sp.n_partials = 1; sp.partials[0].out = pout.data_ptr(); sp.partials[0].lse = plse.data_ptr(); sp.partials[0].count = 1
+            if S == int(a.S.split(",")[0]):
+                pouts = [torch.randn_like(q) for _ in range(a.partials)]; plses = [torch.randn(a.B, 1, a.Hq, device=dev, dtype=torch.float32) for _ in range(a.partials)]
+            sp.n_partials = a.partials
+            for i_ in range(a.partials):
+                sp.partials[i_].out = pouts[i_].data_ptr(); sp.partials[i_].lse = plses[i_].data_ptr(); sp.partials[i_].count = 1; sp.partials[i_].is_f32 = 0
         else:
             sp.lse = lse.data_ptr()
         us = timeit(lambda: _lib.check(lib.hyd_suffix_attn_fwd(C.byref(sp), stream)), a.iters)
