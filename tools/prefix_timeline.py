@@ -121,7 +121,10 @@ def main():
                              parts=[np.median(x) for x in parts], parts_max=[x.max() for x in parts],
                              xcd_start=[float(np.median(start[xcc == x])) if (xcc == x).any() else float("nan") for x in range(8)],
                              xcd_life=[float(np.median(life[xcc == x])) if (xcc == x).any() else float("nan") for x in range(8)],
-                             xcd_end=[float(end[xcc == x].max()) if (xcc == x).any() else float("nan") for x in range(8)]))
+                             xcd_end=[float(end[xcc == x].max()) if (xcc == x).any() else float("nan") for x in range(8)],
+                             xcd_clock=[float(np.median(clock[xcc == x])) if (xcc == x).any() else float("nan") for x in range(8)],
+                             xcd_loop=[float(np.median(parts[2][xcc == x])) if (xcc == x).any() else float("nan") for x in range(8)],
+                             xcd_fixed=[float(np.median((parts[0] + parts[1] + parts[3] + parts[4])[xcc == x])) if (xcc == x).any() else float("nan") for x in range(8)]))
     med = lambda key: float(np.median([r_[key] for r_ in rows_out]))
     print(f"# stamps of {len(recs)} graph replays (medians over replays); real time = s_memrealtime at 100 MHz (10 ns steps)")
     print(f"launch extent, first workgroup start -> last workgroup end   {med('extent'):7.2f} us")
@@ -139,6 +142,10 @@ def main():
           "  ".join(f"{x}: {s_:.2f}/{l_:.2f}/{e_:.2f}" for x, (s_, l_, e_) in enumerate(zip(
               np.median([r_["xcd_start"] for r_ in rows_out], axis=0), np.median([r_["xcd_life"] for r_ in rows_out], axis=0),
               np.median([r_["xcd_end"] for r_ in rows_out], axis=0)))))
+    print("  per XCD: shader clock MHz / key-loop cycles / fixed-part cycles: " +
+          "  ".join(f"{x}: {c_:.0f}/{l_:.0f}/{f_:.0f}" for x, (c_, l_, f_) in enumerate(zip(
+              np.median([r_["xcd_clock"] for r_ in rows_out], axis=0), np.median([r_["xcd_loop"] for r_ in rows_out], axis=0),
+              np.median([r_["xcd_fixed"] for r_ in rows_out], axis=0)))))
     del keep
 
 
