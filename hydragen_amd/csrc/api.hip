@@ -105,6 +105,16 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMa
             const int max_by_len = p->kv_len / 256 > 0 ? p->kv_len / 256 : 1;
             const int want = (int)(kNumCU / units);
             ns = want < max_by_len ? want : max_by_len;
+            // ... but every split is one more fp32 slice of ALL rows written here and read back by the consumer.  With the
+            // workgroups in one round the pass takes about fixed + (kv_len / ns) c + ns s1: c = 13.6 ns per key of a 128-row unit
+            // (C2's key loop), s1 = what a slice costs, calibrated at twice its write + read time at 5 TB/s on the sweeps of
+            // profiles/r05_split_plan_sweep.txt (the consumer's epilogue pays for it in latency as well).  The minimum is at
+            // ns = sqrt(kv_len c / s1): C3 16, a TP = 8 shard of C2 (4/4 heads) 4 instead of 8 (whole call 48.4 -> 43.4 us),
+            // B = 64, 32/8 heads, P = 4096 8 instead of 16 (37.1 -> 30.9), B = 256, 32/32, P = 512 unsplit (67.2 -> 62.8).
+            const double s1_us = (double)p->B * p->nq * p->Hq * p->D * 16.0 / 5.0e6;
+            const double best = sqrt((double)p->kv_len * 0.0136 / s1_us);
+            const int by_cost = best < 1.5 ? 1 : (int)(best + 0.5);
+            if (by_cost < ns) ns = by_cost;
         }
     }
     if (p->cu_seqlens_q) ns = 1;  // merged LSE re-layout needs uniform query counts
