@@ -123,6 +123,29 @@ def test_eight_wave_prefix_kernel_owns_the_top_of_the_register_file():
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_build_refuses_a_compiler_that_touches_the_literal_registers():
+    """csrc/regcheck.py is what build.py runs on the assembly of every (re)compile of the prefix kernels: the real
+    assembly passes; the same text with ONE compiler-looking instruction on v200 planted in an 8-wave kernel, with one on an AGPR in a
+    4-wave kernel, or with a spill in the metadata, is refused -- build.py then deletes objects, stamps and library."""
+    import sys
+    sys.path.insert(0, str(CSRC))
+    from regcheck import RegisterOwnershipError, check_prefix_asm
+
+    asm = _device_asm("prefix_attn_w64.hip")
+    check_prefix_asm(asm, "as compiled")
+    label = re.search(r"^(_ZN3hyd\w*w64x8\w+):", asm, flags=re.M)
+    planted = asm[:label.end()] + "\n\tv_mov_b32_e32 v200, v1\n" + asm[label.end():]
+    with pytest.raises(RegisterOwnershipError, match="v200"):
+        check_prefix_asm(planted, "planted VGPR")
+    label4 = re.search(r"^(_ZN3hyd22prefix_attn_w64_kernel\w+):", asm, flags=re.M)
+    planted = asm[:label4.end()] + "\n\tv_accvgpr_write_b32 a5, v1\n" + asm[label4.end():]
+    with pytest.raises(RegisterOwnershipError, match="AGPR"):
+        check_prefix_asm(planted, "planted AGPR")
+    with pytest.raises(RegisterOwnershipError, match="spills"):
+        check_prefix_asm(asm.replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 2", 1), "planted spill")
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
 def test_gqa_suffix_kernel_names_no_register_by_hand():
     """suffix_attn_gqa.hip streams K and V through LDS landing tiles (LDS-DMA: no destination register) and issues every load that
     lands in registers as plain C++: no accumulator register is allocated at all (round 4's form kept K sets in asm-owned AGPRs and
