@@ -70,10 +70,10 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     const int b = (int)blockIdx.x - hkg * a.B;
     const int hk = hkg * HPW + (HPW == 1 ? 0 : wv), row0 = blockIdx.y * 16;
 
-    int len = a.kv_len;
-    if (a.sl32) len = a.sl32[b];
-    else if (a.sl64) len = (int)a.sl64[b];
-    len = max(0, min(len, a.kv_len));
+    // the sequence's length is requested first and used last: q and the first partials are requested under its round trip
+    int len_raw = a.kv_len;
+    if (a.sl32) len_raw = a.sl32[b];
+    else if (a.sl64) len_raw = (int)a.sl64[b];
 
     // ---- this lane's query row (B operand of S^T = K Q^T: column = row l15, 8 dims of every 32-dim chunk) ----
     const int row = row0 + l15;
@@ -89,60 +89,6 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
             qf[c] = rvalid ? *reinterpret_cast<const u32x4*>(qr + 32 * c) : z;
         }
     }
-
-    // ---- K / V windows of this unit: rows [0, len) are in range, everything else reads as zero ------------------
-    const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
-    const u32x4 krs = make_rsrc_g(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs, (unsigned)len * k_ts2);
-    const u32x4 vrs = make_rsrc_g(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs, (unsigned)len * v_ts2);
-    // Tiny problems (SuffixArgs::pk): the group's shared prefix is walked first, through its own resources, then the
-    // unit's own keys -- the (m, l, O) state simply carries over, and the whole operator is this one launch.
-    const bool has_pre = a.pk != nullptr;
-    const int gi = has_pre ? b / a.p_per : 0;
-    const u32x4 krs_p = make_rsrc_g(static_cast<const uint16_t*>(has_pre ? a.pk : a.k) + (int64_t)gi * a.pk_gs + (int64_t)hk * a.pk_hs,
-                                    has_pre ? (unsigned)a.p_len * k_ts2 : 0u);
-    const u32x4 vrs_p = make_rsrc_g(static_cast<const uint16_t*>(has_pre ? a.pv : a.v) + (int64_t)gi * a.pv_gs + (int64_t)hk * a.pv_hs,
-                                    has_pre ? (unsigned)a.p_len * v_ts2 : 0u);
-    u32x4 krs_c = krs, vrs_c = vrs;  // the segment being walked
-    int seg_len = len;
-    // K and V DMA: instruction i covers tile rows [i * RPI, +RPI) -- whole rows, 1 KiB contiguous when the heads of a token are
-    // (Hkv = 1), RPI row pieces of 2 D bytes otherwise; the LDS image of an instruction is lane-linear, so the XOR swizzles of
-    // the two tiles are applied to the per-lane SOURCE chunk (involutions inside a row).
-    //   K tile: 16-byte chunk j of row r sits at position j ^ sw_k(r) -- the A-operand reads below (16 rows, one chunk
-    //           column per quarter wave) then touch every bank once;  sw_k(r) = r & 15 (D >= 128), (r >> 1) & 7 (D = 64)
-    //   V tile: 64-byte groups swizzled for the transposing reads (as before)
-    const int drow = (lane * 16) / RB, dcp = ((lane * 16) % RB) >> 4;
-    unsigned kvoff[NVD], vvoff[NVD];
-#pragma unroll
-    for (int i = 0; i < NVD; ++i) {
-        const int r_ = i * RPI + drow;
-        const int swk = D >= 128 ? (r_ & 15) : ((r_ >> 1) & 7);
-        kvoff[i] = (unsigned)r_ * k_ts2 + (unsigned)(dcp ^ swk) * 16u;
-        const int sw = D >= 128 ? (r_ & 3) : ((r_ >> 1) & 1);
-        const int vch = (((dcp >> 2) ^ sw) << 2) | (dcp & 3);
-        vvoff[i] = (unsigned)r_ * v_ts2 + (unsigned)vch * 16u;
-    }
-    typedef const __attribute__((address_space(3))) char* lptr_c;
-    const unsigned kt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)ktile);
-    const unsigned vt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)vtile);
-    // K fragment (A operand of S^T = K Q^T): key = 16 h + l15, dims 32 c + 8 g4 .. + 8 = chunk 4 c + g4 of the row
-    unsigned kaddr[2];  // byte address of chunk position 0 of this lane's row, key half h; the chunk's position is XORed in per read
-    const int kswz = D >= 128 ? l15 : ((l15 >> 1) & 7);  // sw_k of rows l15 and 16 + l15 alike
-#pragma unroll
-    for (int h = 0; h < 2; ++h) kaddr[h] = (unsigned)(uintptr_t)(lptr_c)(ktile + (16 * h + l15) * RB);
-    // V^T fragment (A operand of O^T += V^T P^T): d = 16 db + l15, keys {4 g4 + j} (half 0) / {16 + 4 g4 + j} (half 1);
-    // the 16-lane group reads the 4 x 16 block, lane l15 supplies row l15 >> 2, columns 4 (l15 & 3) .. + 4
-    const int trow = 4 * g4 + (l15 >> 2);
-    const int tsw = D >= 128 ? (trow & 3) : ((trow >> 1) & 1);
-    unsigned vaddr[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-        vaddr[db] = (unsigned)(uintptr_t)(lptr_c)(vtile + trow * RB + (((db >> 1) ^ tsw) << 6) + 32 * (db & 1) + 8 * (l15 & 3));
-
-    f32x4 o[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = a.scale_log2e;
 
     // ---- prefix partials (attention.py:21-43) are dealt to the unit's waves: wave w folds partials w, w + WPU, ... into
     // its own (m, l, O) state -- a normalised partial (O_p, lse_p) IS a state (m = lse_p * log2 e, l = 1, O = O_p) -- and the
@@ -185,6 +131,63 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         }
     }
 
+    // ---- K / V windows of this unit: rows [0, len) are in range, everything else reads as zero ------------------
+    // The windows span the cache's kv_len rows, NOT the sequence's length: the first step is requested before the length has
+    // arrived (below), so rows in [len, kv_len) may land in the tiles -- whatever they hold (the tests poison them with NaN): their
+    // scores are replaced by -inf (a select, not arithmetic) and their V rows are zeroed in registers (sanitize, masked steps only).
+    const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
+    const u32x4 krs = make_rsrc_g(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)hk * a.k_hs, (unsigned)a.kv_len * k_ts2);
+    const u32x4 vrs = make_rsrc_g(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)hk * a.v_hs, (unsigned)a.kv_len * v_ts2);
+    // Tiny problems (SuffixArgs::pk): the group's shared prefix is walked first, through its own resources, then the
+    // unit's own keys -- the (m, l, O) state simply carries over, and the whole operator is this one launch.
+    const bool has_pre = a.pk != nullptr;
+    const int gi = has_pre ? b / a.p_per : 0;
+    const u32x4 krs_p = make_rsrc_g(static_cast<const uint16_t*>(has_pre ? a.pk : a.k) + (int64_t)gi * a.pk_gs + (int64_t)hk * a.pk_hs,
+                                    has_pre ? (unsigned)a.p_len * k_ts2 : 0u);
+    const u32x4 vrs_p = make_rsrc_g(static_cast<const uint16_t*>(has_pre ? a.pv : a.v) + (int64_t)gi * a.pv_gs + (int64_t)hk * a.pv_hs,
+                                    has_pre ? (unsigned)a.p_len * v_ts2 : 0u);
+    u32x4 krs_c = krs, vrs_c = vrs;  // the segment being walked
+    int seg_len = 0, seg_cap = 0;  // keys of the segment being walked; rows its window addresses
+    // K and V DMA: instruction i covers tile rows [i * RPI, +RPI) -- whole rows, 1 KiB contiguous when the heads of a token are
+    // (Hkv = 1), RPI row pieces of 2 D bytes otherwise; the LDS image of an instruction is lane-linear, so the XOR swizzles of
+    // the two tiles are applied to the per-lane SOURCE chunk (involutions inside a row).
+    //   K tile: 16-byte chunk j of row r sits at position j ^ sw_k(r) -- the A-operand reads below (16 rows, one chunk
+    //           column per quarter wave) then touch every bank once;  sw_k(r) = r & 15 (D >= 128), (r >> 1) & 7 (D = 64)
+    //   V tile: 64-byte groups swizzled for the transposing reads (as before)
+    const int drow = (lane * 16) / RB, dcp = ((lane * 16) % RB) >> 4;
+    unsigned kvoff[NVD], vvoff[NVD];
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) {
+        const int r_ = i * RPI + drow;
+        const int swk = D >= 128 ? (r_ & 15) : ((r_ >> 1) & 7);
+        kvoff[i] = (unsigned)r_ * k_ts2 + (unsigned)(dcp ^ swk) * 16u;
+        const int sw = D >= 128 ? (r_ & 3) : ((r_ >> 1) & 1);
+        const int vch = (((dcp >> 2) ^ sw) << 2) | (dcp & 3);
+        vvoff[i] = (unsigned)r_ * v_ts2 + (unsigned)vch * 16u;
+    }
+    typedef const __attribute__((address_space(3))) char* lptr_c;
+    const unsigned kt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)ktile);
+    const unsigned vt0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_c)vtile);
+    // K fragment (A operand of S^T = K Q^T): key = 16 h + l15, dims 32 c + 8 g4 .. + 8 = chunk 4 c + g4 of the row
+    unsigned kaddr[2];  // byte address of chunk position 0 of this lane's row, key half h; the chunk's position is XORed in per read
+    const int kswz = D >= 128 ? l15 : ((l15 >> 1) & 7);  // sw_k of rows l15 and 16 + l15 alike
+#pragma unroll
+    for (int h = 0; h < 2; ++h) kaddr[h] = (unsigned)(uintptr_t)(lptr_c)(ktile + (16 * h + l15) * RB);
+    // V^T fragment (A operand of O^T += V^T P^T): d = 16 db + l15, keys {4 g4 + j} (half 0) / {16 + 4 g4 + j} (half 1);
+    // the 16-lane group reads the 4 x 16 block, lane l15 supplies row l15 >> 2, columns 4 (l15 & 3) .. + 4
+    const int trow = 4 * g4 + (l15 >> 2);
+    const int tsw = D >= 128 ? (trow & 3) : ((trow >> 1) & 1);
+    unsigned vaddr[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        vaddr[db] = (unsigned)(uintptr_t)(lptr_c)(vtile + trow * RB + (((db >> 1) ^ tsw) << 6) + 32 * (db & 1) + 8 * (l15 & 3));
+
+    f32x4 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = a.scale_log2e;
+
     // ---- one 32-key step --------------------------------------------------------------------------------------------------
     // issue:   2 NVD LDS-DMA instructions, K rows -> K tile, V rows -> V tile (zero fill past the segment's end)
     // collect: the landed tiles -> registers (K: 2 NCH ds_read_b128 in the A-operand layout; V^T: 2 NDB transposing reads), after
@@ -216,6 +219,21 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         }
         // every read has returned before the tiles are handed to the next DMA (asm: hipcc does not order it against them otherwise)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // a step that reaches past the segment's keys: zero the V rows of keys >= seg_len (dword w of a V^T fragment holds keys
+    // key0 + 4 g4 + {0,1} / {2,3} / 16 + {0,1} / 16 + {2,3}, the first in its low half)
+    auto sanitize = [&](int key0) __attribute__((always_inline)) {
+        const int kb = key0 + 4 * g4;
+        unsigned msk[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int ka = kb + (w >> 1) * 16 + (w & 1) * 2;
+            msk[w] = (ka < seg_len ? 0x0000ffffu : 0u) | (ka + 1 < seg_len ? 0xffff0000u : 0u);
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) vf[db][w] &= msk[w];
     };
     auto compute = [&](int key0) __attribute__((always_inline)) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -306,30 +324,39 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         }
         pre_folded = true;
     };
+    int len = 0;
     for (int seg = has_pre ? 0 : 1; seg < 2; ++seg) {  // every segment drains its own pipeline
-        if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_len = a.p_len; }
-        else { krs_c = krs; vrs_c = vrs; seg_len = len; }
         constexpr int stride = 32 * WPU;
         const int k_first = wave * 32;
-        const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
-        if (nst > 0) {
-            issue(k_first);
-            for (int j = 0; j < nst; ++j) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step j's tiles have landed (and, the first time, q and the first partial)
-                // hipcc counts only its own loads (q, the first partial): make it settle them HERE, where nothing is in flight -- a
-                // counted wait of its own further down would also wait for the next step's DMAs, which it does not know about
+        if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_cap = a.p_len; }
+        else { krs_c = krs; vrs_c = vrs; seg_cap = a.kv_len; }
+        // The first step is requested for whatever the window holds, BEFORE the sequence's length is known: the length, q, the first
+        // partials and the first tiles then share one round trip instead of two.  (A sequence shorter than k_first keys wastes it.)
+        const bool spec = seg_cap > k_first;
+        if (spec) issue(k_first);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... all landed
+        // hipcc counts only its own loads (the length, q, the first partials): make it settle them HERE, where nothing is in flight -- a
+        // counted wait of its own further down would also wait for the next step's DMAs, which it does not know about
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) asm volatile("" ::"v"(qf[c]));
-                if (!pre_folded) fold_pre();
-                collect();
-                if (j + 1 < nst) issue(k_first + (j + 1) * stride);  // in flight while step j is computed
-                compute(k_first + j * stride);
-            }
+        for (int c = 0; c < NCH; ++c) asm volatile("" ::"v"(qf[c]));
+        if (seg == 1) {
+            asm volatile("" : "+v"(len_raw));
+            len = max(0, min(len_raw, a.kv_len));
+        }
+        seg_len = seg == 0 ? a.p_len : len;
+        if (!pre_folded) fold_pre();
+        const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
+        for (int j = 0; j < nst; ++j) {
+            const int key0 = k_first + j * stride;
+            if (j > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step j's tiles have landed
+            collect();
+            if (key0 + 32 > seg_len) sanitize(key0);
+            if (j + 1 < nst) issue(key0 + stride);  // in flight while step j is computed
+            compute(key0);
         }
     }
     // the keys-only state (the LSE output is the suffix pass's own; when it is asked for, no partial was folded above)
     const float m_s = m_run, l_s = l_run;
-    if (!pre_folded) fold_pre();  // a wave without a key step (hipcc's own wait covers the request)
 
     // ---- this wave's other partials (all of them when the LSE output is asked for) ---------------------------------------
     for (int i = wave + max(npre, 0) * WPU; i < np; i += 2 * WPU) {
