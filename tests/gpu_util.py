@@ -7,11 +7,12 @@ TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
 # Tolerances.  fp16: the reference's own bar (tests/test_attention.py:36-38,182-187): every |d| <= 2e-3, mean rdiff <= 5e-3.
 # bf16 (8 mantissa bits; the reference states no bf16 bar): every |d| <= 4 half-ulps of the largest expected output,
 # i.e. max|want| * 2^-7 (one output rounding is 1 half-ulp; measured at C2: 2.9 half-ulps), mean rdiff <= 1e-2 and
-# relative L2 error <= 5e-3 against the float64 oracle on identical (bf16-rounded) inputs -- set from the 8000-seed
-# soak (tools/soak.py: relative L2 peaks at 3.4e-3) and the C2 measurement (2.85e-3, bench.py `accuracy`).
+# relative L2 error <= 4e-3 against the float64 oracle on identical (bf16-rounded) inputs -- set from the soaks
+# (tools/soak.py: relative L2 peaks at 3.4e-3 over 8000 seeds in rounds 3-4, 3.2e-3 over 6500 in round 5) and the C2
+# measurement (2.85e-3, bench.py `accuracy`); 5e-3 until round 5.
 ATOL = {"f16": 2e-3}
 RTOL_MEAN = {"f16": 5e-3, "bf16": 1e-2}
-REL_L2 = {"f16": 1e-3, "bf16": 5e-3}
+REL_L2 = {"f16": 1e-3, "bf16": 4e-3}
 
 
 def atol(dtype, want):
@@ -68,7 +69,7 @@ def assert_close(got, want, dtype, what="", rtol_mean=None):
 def assert_close_l2(got, want, dtype, what=""):
     """Maximum absolute error (fp16: the reference's atol, scaled by max |want| when outputs exceed 1; bf16: 4 half-ulps of
     max |want|) and relative L2 error ||got - want|| / ||want|| <= 1e-3 for fp16 (the figure BASELINE.json states),
-    5e-3 for bf16.  Used where tensors are small: the
+    4e-3 for bf16.  Used where tensors are small: the
     reference's third figure, the MEAN element-wise relative difference (tests/test_attention.py:183-185), is kept
     for the reference-shaped cases but is dominated by outputs near zero on tensors of a few hundred elements (a
     5000-seed soak, tools/soak.py: relative L2 peaks at 4.0e-4 / 3.3e-3 while the mean relative difference of the
