@@ -669,7 +669,7 @@ PREFLIGHT_STAGE_SECONDS = 60.0
 
 def preflight(args, rank, world, backend, dev):
     """N > 1, before anything is timed: the pieces a first run on a multi-GPU node can fail in, one by one, each under its own
-    60 s watchdog, so that a failure NAMES its stage instead of hanging the job or surfacing as a wrong number later
+    60 s watchdog (180 s for the process group's bootstrap), so that a failure NAMES its stage instead of hanging the job or surfacing as a wrong number later
     (the bootstrap and collectives of /root/reference/hydragen/utils.py:118-133, tp.py:108-112, the in-graph collective of
     llama.py:849-854).  Rank 0 prints one `[preflight] {json}` line per stage.  Stages:
       devices          visible devices >= N (one-device self-test mode excepted)
@@ -697,10 +697,10 @@ def preflight(args, rank, world, backend, dev):
         sys.stdout.flush()
         os._exit(3)
 
-    def staged(stage, fn, optional_flag=None):
+    def staged(stage, fn, optional_flag=None, seconds=PREFLIGHT_STAGE_SECONDS):
         """Run one stage under the watchdog.  Hard stages die on any failure; optional ones only on a hang."""
         hint = f"--{optional_flag.replace('_', '-')} skips this stage" if optional_flag else ""
-        timer = threading.Timer(PREFLIGHT_STAGE_SECONDS, lambda: die(stage, f"no answer within {PREFLIGHT_STAGE_SECONDS:.0f} s", hint))
+        timer = threading.Timer(seconds, lambda: die(stage, f"no answer within {seconds:.0f} s", hint))
         timer.daemon = True
         timer.start()
         t0 = time.perf_counter()
@@ -801,7 +801,7 @@ def preflight(args, rank, world, backend, dev):
             setattr(args, flag, True)
 
     staged("devices", st_devices)
-    staged("rccl_init", st_init)
+    staged("rccl_init", st_init, seconds=3 * PREFLIGHT_STAGE_SECONDS)  # (the first RCCL bootstrap of a cold node detects the topology)
     staged("peer_access", st_peer)
     if not args.no_xgmi:
         staged("xgmi_allreduce", st_xgmi, "no_xgmi")
