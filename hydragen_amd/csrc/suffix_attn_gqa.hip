@@ -459,6 +459,9 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
     SuffixArgs a = a_in;
     const int chunks = (a.rows + 15) / 16;
     bool few_units = gqa_few_units(a, chunks);
+#ifdef HYD_ABLATION_BUILD
+    if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
+#endif
     // kv heads of a sequence per workgroup (one-wave units of the unique phase).  Measured with this kernel (profiles/r05_gqa_hpw.txt,
     // us at S = 32 / 128 / 256): 8 kv heads: 1 head per workgroup 61 / 197 / 364, 2: 60 / 185 / 355, 4: 64 / 184 / 352, 8: 71 / 187 / 341 -- a
     // workgroup that fills the CU's LDS alone (8 x 16 KB) leaves it idle between workgroups, which short suffixes pay for; 16 kv heads:
@@ -470,7 +473,6 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
         if (D == 256 && hpw > 2) hpw = 2;  // 32 KB of tiles per wave
     }
 #ifdef HYD_ABLATION_BUILD
-    if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
     if (const char* e = getenv("HYD_GQA_HPW")) hpw = few_units ? 1 : atoi(e);
 #endif
     dim3 grid((unsigned)a.B * (unsigned)(a.Hkv / hpw), chunks, 1);
