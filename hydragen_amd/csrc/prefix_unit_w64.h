@@ -418,6 +418,63 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     // 32-key blocks per wave: its half of every 128-key tile (KG = 2) or all keys (KG = 1); even, the loop runs in pairs
     const int NB = KG == 2 ? 2 * ((nkeys + 127) >> 7) : 2 * ((nkeys + 63) >> 6);
 
+    // ---- LDS map (bytes) ------------------------------------------------------------------------------------
+    // KG = 2: KA[2 tiles x 64 rows] | KB[2 tiles x 64 rows] | V[2 tiles x 128 rows] | mlbuf.  KA: rows 0..63 of a
+    // 128-key K tile (kg = 0 waves), KB: rows 64..127 (kg = 1 waves).  Ring slot s (block b, s = b & 3): tile buffer
+    // s >> 1, rows [(s & 1) * 32, +32) of each 64-row half.
+    // KG = 1: K[4 slots of 32 rows] | V[4 slots of 32 rows] | mlbuf.
+    constexpr int KH_BYTES = 64 * RB;
+    constexpr int V_BYTES = KG == 2 ? 128 * RB : 64 * RB;  // two ring slots of V
+    constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = KG == 2 ? 4 * KH_BYTES : 2 * KH_BYTES;
+    typedef const __attribute__((address_space(3))) char* lptr_c;
+    auto slot_k = [](int s) { return KG == 2 ? (s >> 1) * KH_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
+    auto slot_v = [](int s) { return KG == 2 ? (s >> 1) * V_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
+
+    // ---- staging: global -> LDS DMA, BROWS rows per tensor and iteration, NLB instructions per wave ----------
+    // The LDS image of a wave instruction is lane-linear (base + lane * 16), so the XOR swizzles are applied to the
+    // per-lane SOURCE chunk (involutions inside a row).  Instruction q = wave * NLB + i covers rows
+    // rr = q * RPI + [0, RPI) of the staged rows: half h = rr >> 5 (KG = 2), row r32 = rr & 31.
+    // ORDER OF THE PROLOGUE: a workgroup's first 4 us are ~300 set-up instructions and then the launch's cold burst (every
+    // workgroup fetches its 32 KB of Q rows at once: 8 MB at ~5 TB/s; profiles/r05_prefix_timeline.md).  What the first
+    // iteration waits for -- K block 0 and the Q rows -- is issued first, from the K half of the staging set-up alone; V's
+    // offsets, the fragment addresses and the softmax state are computed under the burst (sched_barrier below: hipcc may not
+    // hoist them back).  Stamps, start -> first barrier passed: C2 4.13 -> 3.81 us, C3 3.79 -> 3.58 us per workgroup.
+    const int drow = (lane * 16) / RB;        // row inside the instruction
+    const int dcp = ((lane * 16) % RB) >> 4;  // 16-byte slot inside the row (LDS side)
+    unsigned koffb[NLB], voffb[NLB];  // per-lane source byte offsets relative to the block's first row
+    unsigned kdst[NLB], vdst[NLB];    // wave-uniform LDS byte address of the instruction in ring slot 0 (piece i = piece 0 + 1024 i)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_c)smem;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int q = wave * NLB + i;
+        const int rr = q * RPI + drow, h = KG == 2 ? rr >> 5 : 0, r32 = rr & 31;
+        const int kch = D >= 128 ? (dcp ^ (r32 & 15)) : (dcp ^ ((r32 >> 1) & 7));
+        const int drr = h * 64 + r32;  // row inside the 128-key tile (KG = 2) / the block (KG = 1)
+        // piece i is issued with the immediate offset 1024 i (dma16w): drr >= RPI i and a row is >= RB bytes, so >= 0
+        koffb[i] = (unsigned)(((int64_t)drr * a.k_ts + kch * 8) * 2) - 1024u * i;
+        const int qh = KG == 2 ? (q * RPI) >> 5 : 0, qr = (q * RPI) & 31;  // wave-uniform
+        kdst[i] = __builtin_amdgcn_readfirstlane(lds0 + (qh ? KB_OFF : KA_OFF) + qr * RB);
+    }
+    // One buffer resource per tensor for the whole pass: rows [kbeg, kend) of this (group, head); a block's first row
+    // goes into the scalar offset.  Blocks / rows at or past the end read as zeros.
+    const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
+    const u32x4 krs = make_rsrc_w(reinterpret_cast<const char*>(k16) + (int64_t)kbeg * a.k_ts * 2,
+                                  nkeys > 0 ? (unsigned)(nkeys - 1) * k_ts2 + RB : 0u);
+    auto row0_of = [&](int b) -> int { return KG == 2 ? (b >> 1) * 128 + (b & 1) * 32 : b * 32; };
+    // a block whose first row is past the keys gets an offset past num_records: the whole instruction zero-fills
+    auto soff_of = [&](int b, unsigned ts2) -> unsigned {
+        const int r0 = row0_of(b);
+        return __builtin_amdgcn_readfirstlane(r0 < nkeys + 128 ? (unsigned)r0 * ts2 : 0x7fff0000u);
+    };
+    auto dma_kblock = [&](int b) __attribute__((always_inline)) {
+        dma_m0(kdst[0] + slot_k(b & 3));
+        static_for<NLB>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value;
+            dma16w<1024 * i, true>(krs, koffb[i], soff_of(b, k_ts2));  // padded: the prologue's scalars may come straight from a v_readlane / v_readfirstlane
+        });
+    };
+    if (NB > 0) dma_kblock(0);
+
     // ---- this lane's query rows (one per query block), fetched straight into AGPRs ---------------------------------
     // (B operands of the QK^T MFMAs for the whole kernel.)  Rows past the end are clamped to the last valid row: every
     // lane computes an independent query row, and an invalid lane never stores.
@@ -452,17 +509,34 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         });
     }
 
-    // ---- LDS map (bytes) ------------------------------------------------------------------------------------
-    // KG = 2: KA[2 tiles x 64 rows] | KB[2 tiles x 64 rows] | V[2 tiles x 128 rows] | mlbuf.  KA: rows 0..63 of a
-    // 128-key K tile (kg = 0 waves), KB: rows 64..127 (kg = 1 waves).  Ring slot s (block b, s = b & 3): tile buffer
-    // s >> 1, rows [(s & 1) * 32, +32) of each 64-row half.
-    // KG = 1: K[4 slots of 32 rows] | V[4 slots of 32 rows] | mlbuf.
-    constexpr int KH_BYTES = 64 * RB;
-    constexpr int V_BYTES = KG == 2 ? 128 * RB : 64 * RB;  // two ring slots of V
-    constexpr int KA_OFF = 0, KB_OFF = 2 * KH_BYTES, V_OFF = KG == 2 ? 4 * KH_BYTES : 2 * KH_BYTES;
-    typedef const __attribute__((address_space(3))) char* lptr_c;
-    auto slot_k = [](int s) { return KG == 2 ? (s >> 1) * KH_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
-    auto slot_v = [](int s) { return KG == 2 ? (s >> 1) * V_BYTES + (s & 1) * 32 * RB : s * 32 * RB; };
+    __builtin_amdgcn_sched_barrier(0);  // everything below is computed under the flight of K block 0 and Q
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int q = wave * NLB + i;
+        const int rr = q * RPI + drow, h = KG == 2 ? rr >> 5 : 0, r32 = rr & 31;
+        const int vs_ = D >= 128 ? (r32 & 3) : ((r32 >> 1) & 1);
+        const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
+        const int drr = h * 64 + r32;
+        voffb[i] = (unsigned)(((int64_t)drr * a.v_ts + vch * 8) * 2) - 1024u * i;
+        const int qh = KG == 2 ? (q * RPI) >> 5 : 0, qr = (q * RPI) & 31;  // wave-uniform
+        vdst[i] = __builtin_amdgcn_readfirstlane(lds0 + V_OFF + (qh * 64 + qr) * RB);
+    }
+    const u32x4 vrs = make_rsrc_w(reinterpret_cast<const char*>(v16) + (int64_t)kbeg * a.v_ts * 2,
+                                  nkeys > 0 ? (unsigned)(nkeys - 1) * v_ts2 + RB : 0u);
+    auto dma_block = [&](int b, bool isv) __attribute__((always_inline)) {
+        dma_m0(isv ? vdst[0] + slot_v(b & 3) : kdst[0] + slot_k(b & 3));
+        static_for<NLB>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value;
+            if (isv) dma16w<1024 * i, true>(vrs, voffb[i], soff_of(b, v_ts2));
+            else dma16w<1024 * i, true>(krs, koffb[i], soff_of(b, k_ts2));
+        });
+    };
+    if (NB > 0) {  // the rest of the cold start (see "Cold start" at the pipeline): behind K block 0 and Q, not waited for with them
+        dma_block(1, false);
+        dma_block(2, false);
+        dma_block(0, true);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- per-lane LDS byte addresses of the MFMA fragments (ring slot 0) -------------------------------
     const int ksw = D >= 128 ? (l31 & 15) : ((l31 >> 1) & 7);
@@ -478,52 +552,6 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     for (int db = 0; db < NDB; ++db)
         vaddr[db] = (unsigned)(uintptr_t)(lptr_c)(smem + V_OFF + (kg * 64 + 4 * hi + (i16 >> 2)) * RB +
                                                   ((db ^ vsw) << 6) + 32 * (g16 & 1) + 8 * (i16 & 3));
-
-    // ---- staging: global -> LDS DMA, BROWS rows per tensor and iteration, NLB instructions per wave ----------
-    // The LDS image of a wave instruction is lane-linear (base + lane * 16), so the XOR swizzles are applied to the
-    // per-lane SOURCE chunk (involutions inside a row).  Instruction q = wave * NLB + i covers rows
-    // rr = q * RPI + [0, RPI) of the staged rows: half h = rr >> 5 (KG = 2), row r32 = rr & 31.
-    const int drow = (lane * 16) / RB;        // row inside the instruction
-    const int dcp = ((lane * 16) % RB) >> 4;  // 16-byte slot inside the row (LDS side)
-    unsigned koffb[NLB], voffb[NLB];  // per-lane source byte offsets relative to the block's first row
-    unsigned kdst[NLB], vdst[NLB];    // wave-uniform LDS byte address of the instruction in ring slot 0 (piece i = piece 0 + 1024 i)
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_c)smem;
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const int q = wave * NLB + i;
-        const int rr = q * RPI + drow, h = KG == 2 ? rr >> 5 : 0, r32 = rr & 31;
-        const int kch = D >= 128 ? (dcp ^ (r32 & 15)) : (dcp ^ ((r32 >> 1) & 7));
-        const int vs_ = D >= 128 ? (r32 & 3) : ((r32 >> 1) & 1);
-        const int vch = (((dcp >> 2) ^ vs_) << 2) | (dcp & 3);
-        const int drr = h * 64 + r32;  // row inside the 128-key tile (KG = 2) / the block (KG = 1)
-        // piece i is issued with the immediate offset 1024 i (dma16w): drr >= RPI i and a row is >= RB bytes, so >= 0
-        koffb[i] = (unsigned)(((int64_t)drr * a.k_ts + kch * 8) * 2) - 1024u * i;
-        voffb[i] = (unsigned)(((int64_t)drr * a.v_ts + vch * 8) * 2) - 1024u * i;
-        const int qh = KG == 2 ? (q * RPI) >> 5 : 0, qr = (q * RPI) & 31;  // wave-uniform
-        kdst[i] = __builtin_amdgcn_readfirstlane(lds0 + (qh ? KB_OFF : KA_OFF) + qr * RB);
-        vdst[i] = __builtin_amdgcn_readfirstlane(lds0 + V_OFF + (qh * 64 + qr) * RB);
-    }
-    // One buffer resource per tensor for the whole pass: rows [kbeg, kend) of this (group, head); a block's first row
-    // goes into the scalar offset.  Blocks / rows at or past the end read as zeros.
-    const unsigned k_ts2 = (unsigned)(a.k_ts * 2), v_ts2 = (unsigned)(a.v_ts * 2);
-    const u32x4 krs = make_rsrc_w(reinterpret_cast<const char*>(k16) + (int64_t)kbeg * a.k_ts * 2,
-                                  nkeys > 0 ? (unsigned)(nkeys - 1) * k_ts2 + RB : 0u);
-    const u32x4 vrs = make_rsrc_w(reinterpret_cast<const char*>(v16) + (int64_t)kbeg * a.v_ts * 2,
-                                  nkeys > 0 ? (unsigned)(nkeys - 1) * v_ts2 + RB : 0u);
-    auto row0_of = [&](int b) -> int { return KG == 2 ? (b >> 1) * 128 + (b & 1) * 32 : b * 32; };
-    // a block whose first row is past the keys gets an offset past num_records: the whole instruction zero-fills
-    auto soff_of = [&](int b, unsigned ts2) -> unsigned {
-        const int r0 = row0_of(b);
-        return __builtin_amdgcn_readfirstlane(r0 < nkeys + 128 ? (unsigned)r0 * ts2 : 0x7fff0000u);
-    };
-    auto dma_block = [&](int b, bool isv) __attribute__((always_inline)) {
-        dma_m0(isv ? vdst[0] + slot_v(b & 3) : kdst[0] + slot_k(b & 3));
-        static_for<NLB>([&](auto I_) __attribute__((always_inline)) {
-            constexpr int i = decltype(I_)::value;
-            if (isv) dma16w<1024 * i, PERSIST>(vrs, voffb[i], soff_of(b, v_ts2));
-            else dma16w<1024 * i, PERSIST>(krs, koffb[i], soff_of(b, k_ts2));
-        });
-    };
 
     // Online-softmax state per query block, in RAW score units (before the scale): the reference maximum m_raw (equal in
     // the two lanes of a row), nms = -sc * m_raw and the threshold thr = m_raw + kTau / sc above which a block's lane
@@ -809,17 +837,11 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     const int kwave = kbeg + kg * 64;  // first key of this wave's half of tile 0
     // Iterations i = -1 .. NB; the pipeline's fill (i = -1: QK(0) only; i = 0: QK(1) + softmax(0)) and drain
     // (i = NB-1: softmax + PV, no QK; i = NB: PV(NB-1) only) run their own, shorter instantiations of the iteration.
-    // Cold start: the first iteration (QK(0) alone) needs the Q fragments and K block 0 only.  K blocks 1, 2 and V
+    // Cold start (issued in the prologue, above): the first iteration (QK(0) alone) needs the Q fragments and K block 0 only.  K blocks 1, 2 and V
     // block 0 are issued behind them and the wait leaves those three blocks in flight (vector-memory operations retire
     // in issue order): the prologue is a bandwidth burst of every workgroup of the launch at once (~11 B / cycle / CU),
     // so every KiB not waited for is ~90 cycles.  The counted wait that ends iteration -1 covers them; that iteration
     // therefore does not prefetch block 1's first fragments in its tail (FL_FIRST), they are read behind its barrier.
-    if (NB > 0) {
-        dma_block(0, false);
-        dma_block(1, false);
-        dma_block(2, false);
-        dma_block(0, true);
-    }
     static_for<QB * NDB>([&](auto I_) { regs.template zero<decltype(I_)::value>(); });  // under the first loads' flight
     stampk(1);
     if (NB > 0) dma_wait_w<3 * NLB>();
