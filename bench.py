@@ -95,6 +95,9 @@ def parse():
                     help="steps replay the two-stream form of the operator instead of the one-call form (A/B; DESIGN 4.8)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not count HBM bytes with rocprofv3 --pmc child passes of this command (then: the committed passes, if they match)")
+    ap.add_argument("--kv-candidates", type=int, default=None,
+                    help="candidate placements tried for the unique K|V arena before anything is timed (hydragen_amd/placement.py; "
+                         "default: the package's, 6; 1 = plain allocation)")
     ap.add_argument("--trials", type=int, default=3, help="repetitions of the K-step schedule after the headline region (spread)")
     ap.add_argument("--protocol-iters", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -258,7 +261,13 @@ def main():
     dt = torch.bfloat16
     torch.manual_seed(1234 + rank)
     q = torch.randn(B, 1, Hq, D, device=dev, dtype=dt)
-    kv = torch.randn(2, B, S, Hkv, D, device=dev, dtype=dt)  # one arena, K | V, as PerLayerKVCache allocates a layer's unique caches
+    # one arena, K | V, placed as PerLayerKVCache places a layer's unique caches (hydragen_amd/placement.py: candidates timed with
+    # the suffix pass before anything else is allocated or measured; the report goes on the result line)
+    from hydragen_amd import placement
+    if args.kv_candidates is not None:
+        placement.set_candidates(args.kv_candidates)
+    (kv,), kv_place = placement.place_kv_arenas(1, (B, S, Hkv, D), dt, dev, Hq, zero=False)
+    kv.normal_()
     k, v = kv[0], kv[1]
     sk = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
     sv = torch.randn(1, P, Hkv, D, device=dev, dtype=dt)
@@ -424,6 +433,10 @@ def main():
         "attn_us_per_step": elapsed / args.steps * 1e6,
         "prefix_us": sum(pre_ms) / n_ev * 1e3,
         "suffix_us_mean": sum(suf_ms) / n_ev * 1e3,
+        # where the unique K|V arena sits in HBM was chosen by timing candidates (us of one suffix pass over all keys each), before the timed region
+        "kv_placement": ({"candidates": kv_place["candidates"], "probe_us": kv_place["probe_us"], "kept": kv_place["kept"][0],
+                          "spacer_gib": round(kv_place["spacer_bytes"] / 2**30, 1)} if kv_place.get("probed") else
+                         {"candidates": 1, "why": kv_place.get("why")}),
         "step_forms": {"graph_replay_steps": args.steps - n_ev,
                        "graph_form": "one-call form (hyd_decode_attn_fused: prefix pass, then suffix pass with the merge in its epilogue)"
                        if not args.two_stream else
@@ -597,7 +610,7 @@ def _live_traffic(args):
     child = [sys.executable, str(REPO / "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
              "--prefix", str(args.prefix), "--max-suffix", str(args.max_suffix), "--qheads", str(args.qheads), "--kvheads", str(args.kvheads),
              "--dim", str(args.dim), "--trials", "0", "--no-cpu-baseline", "--no-protocol", "--no-model", "--no-accuracy",
-             "--no-paper-sweep", "--no-nosharing", "--no-live-traffic"]
+             "--no-paper-sweep", "--no-nosharing", "--no-live-traffic", "--kv-candidates", "1"]  # (bytes per launch do not depend on the placement; its probe launches would)
     env = dict(os.environ, TMPDIR="/tmp")
     means = {}
     try:

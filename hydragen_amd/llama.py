@@ -23,7 +23,7 @@ from typing import List, Optional, Union
 import torch
 from torch import Tensor, nn
 
-from . import layer_ops
+from . import layer_ops, placement
 from .attention import hydragen_attention
 from .flash import flash_attention, flash_attention_seqlen
 from .tp import all_reduce_sum, check_collectives
@@ -218,13 +218,15 @@ class PerLayerKVCache(nn.Module):
     """llama.py:173-346."""
 
     def __init__(self, max_unique_batch_size, max_unique_seq_length, max_shared_batch_sizes, max_shared_seq_lengths,
-                 n_kv_heads, head_dim, device, dtype):
+                 n_kv_heads, head_dim, device, dtype, arena: Optional[Tensor] = None):
         super().__init__()
         shape = (max_unique_batch_size, max_unique_seq_length, n_kv_heads, head_dim)
-        # One allocation, K | V (the reference's two attribute names, llama.py:186-198, stay as views).  Neutral for speed: round 4
-        # suspected that two separate GiB-sized allocations decide the grouped-query suffix kernel's rate; measured on four boxes in
-        # round 5, neither the arena nor any K-V gap or batch stride does (profiles/r05_gqa_placement.md).
-        arena = torch.zeros((2,) + shape, dtype=dtype, device=device)
+        # One allocation, K | V (the reference's two attribute names, llama.py:186-198, stay as views).  The arena itself is neutral
+        # for speed (no K-V gap or batch stride matters); WHERE it sits in HBM is not (profiles/r05_gqa_placement.md): `setup_caches`
+        # hands in arenas chosen by hydragen_amd/placement.py; without one, a plain allocation as the reference's.
+        if arena is None:
+            arena = torch.zeros((2,) + shape, dtype=dtype, device=device)
+        assert tuple(arena.shape) == (2,) + shape and arena.dtype == dtype, f"{tuple(arena.shape)} {arena.dtype}"
         self.register_buffer("per_completion_k_cache", arena[0])
         self.register_buffer("per_completion_v_cache", arena[1])
         self.shared_caches = nn.ModuleList([
@@ -672,13 +674,21 @@ class HydragenLlamaForCausalLM(nn.Module):
         """Allocate the unique KV cache and the shared cache levels at every layer (llama.py:921-955)."""
         self.maybe_invalidate()
         max_unique_seq_length = (max_unique_seq_length + 15) // 16 * 16
+        head_dim = self.config.hidden_size // self.get_num_heads()
+        device, dtype = self.lm_head.weight.device, self.lm_head.weight.dtype
+        # the layers' unique caches, placed where the suffix pass streams them fastest (placement.py: more candidates than layers
+        # are allocated, each timed once with the suffix pass over all of its keys, the slowest go back; off the data path)
+        self.kv_cache_allocated = False
         for layer in self.model.layers:
+            layer.self_attn.kv_cache = None  # a second setup_caches: the old arenas are free before the candidates are made
+        arenas, self.kv_placement = placement.place_kv_arenas(
+            len(self.model.layers), (max_unique_batch_size, max_unique_seq_length, self.config.num_key_value_heads, head_dim),
+            dtype, device, self.config.num_attention_heads)
+        for layer, arena in zip(self.model.layers, arenas):
             layer.self_attn.kv_cache = PerLayerKVCache(
                 max_unique_batch_size=max_unique_batch_size, max_unique_seq_length=max_unique_seq_length,
                 max_shared_batch_sizes=max_shared_batch_sizes, max_shared_seq_lengths=max_shared_seq_lengths,
-                n_kv_heads=self.config.num_key_value_heads,
-                head_dim=self.config.hidden_size // self.get_num_heads(),
-                device=self.lm_head.weight.device, dtype=self.lm_head.weight.dtype)
+                n_kv_heads=self.config.num_key_value_heads, head_dim=head_dim, device=device, dtype=dtype, arena=arena)
         self.kv_cache_allocated = True
 
     def empty_shared_cache(self):

@@ -16,6 +16,8 @@ def main(path, tag, steps, warmup):
     B, P, S, Hq, Hkv, D, e = 1024, 2048, 128, 32, 32, 128, 2
     vals = {}
     for line in open(path):
+        if "[set-up" in line:  # placement probes (tools/rocprof_summary.py): not launches of the schedule
+            continue
         parts = line.split()
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if c in parts:

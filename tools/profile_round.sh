@@ -23,7 +23,7 @@ DB=$(find /tmp/prof_stats -name '*.db' | head -1)
 echo "# rocprofv3 --pmc passes (separate runs of: $CMD). FETCH_SIZE/WRITE_SIZE in KB per launch; gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)"
 for C in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY"; do
   D=/tmp/prof_pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C -d $D -o run -- $CMD > /dev/null 2>$D.log
+  rocprofv3 --pmc $C -d $D -o run -- $CMD --kv-candidates 1 > /dev/null 2>$D.log   # (bytes per launch do not depend on where the cache sits)
   DB=$(find $D -name '*.db' | head -1)
   if [ -n "$DB" ]; then python $REPO/tools/rocprof_summary.py pmc $DB _attn; else echo "# pass '$C' produced no db: $(tail -2 $D.log | tr '\n' ' ')"; fi
 done
