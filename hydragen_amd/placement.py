@@ -133,7 +133,16 @@ def place_kv_arenas(count: int, shape: Sequence[int], dtype: torch.dtype, device
             torch.cuda.empty_cache()
             return plain("out of memory while allocating candidates")
     with torch.cuda.device(dev):
-        times = [float(probe(c)) for c in cands]
+        try:
+            times = [float(probe(c)) for c in cands]
+        except Exception as ex:  # noqa: BLE001 -- a shape the suffix pass refuses must not cost the caches: first come, first kept
+            out = cands[:count]
+            del cands, spacers
+            torch.cuda.empty_cache()
+            if zero:
+                for a in out:
+                    a.zero_()
+            return out, {"candidates": count, "probed": False, "why": f"probe failed: {type(ex).__name__}: {str(ex)[:120]}"}
         kept = choose(times, count)
         out = [cands[i] for i in kept]
         del cands, spacers

@@ -69,6 +69,11 @@ def test_fastest_candidates_are_kept_zeroed_and_the_rest_released(monkeypatch):
         seen.clear()
         arenas, rep = P.place_kv_arenas(4, (64, 128, 2, 128), torch.bfloat16, "cuda:0", 8, probe=lambda a: [seen.append(a.data_ptr()), float(len(seen) % 3)][1])
         assert rep["candidates"] == 6 and rep["kept"] == [0, 2, 3, 5] and [a.data_ptr() for a in arenas] == [seen[i] for i in rep["kept"]]
+        # a probe that cannot run leaves plain caches behind, not an exception
+        def broken(a):
+            raise RuntimeError("no such kernel")
+        arenas, rep = P.place_kv_arenas(2, (64, 128, 2, 128), torch.bfloat16, "cuda:0", 8, probe=broken)
+        assert len(arenas) == 2 and not rep["probed"] and "no such kernel" in rep["why"] and not any(a.any() for a in arenas)
     finally:
         P.set_candidates(old)
 
