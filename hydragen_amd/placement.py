@@ -28,7 +28,8 @@ from torch import Tensor
 _candidates = int(os.environ.get("HYDRAGEN_KV_CANDIDATES", "6"))
 SPAN_GIB = 48.0
 EXTRA_FRACTION = 0.5
-MIN_ARENA_BYTES = 192 << 20   # below this a cache lives in the 256 MB memory-side cache: placement does not show
+MIN_ARENA_BYTES = 512 << 20   # at or near the 256 MB memory-side cache's size placement does not show (a 268 MB arena, the C5 TP = 8
+                              # slice: six candidates within 2 %, nothing gained -- profiles/r05_kv_placement_probe.md); measured gains are at 2 GiB
 MAX_FREE_FRACTION = 0.5       # of the device's free memory, the most the candidates + spacers may take transiently
 
 
