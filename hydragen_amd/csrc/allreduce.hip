@@ -139,11 +139,20 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
             const int64_t e0 = s0 + i * 8;
             if constexpr (std::is_same<T, float>::value) {
                 f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-                for (int p = 0; p < a.world; ++p) {
-                    const float* src = reinterpret_cast<const float*>(a.block[p] + kArHeaderPad) + e0;
-                    x0 += *reinterpret_cast<const f32x4*>(src);
-                    x1 += *reinterpret_cast<const f32x4*>(src + 4);
-                }
+                f32x4 w0[kArMaxWorld], w1[kArMaxWorld];
+#pragma unroll
+                for (int p = 0; p < kArMaxWorld; ++p)  // all peers' loads (2 x 16 B each) in flight together
+                    if (p < a.world) {
+                        const float* src = reinterpret_cast<const float*>(a.block[p] + kArHeaderPad) + e0;
+                        w0[p] = *reinterpret_cast<const f32x4*>(src);
+                        w1[p] = *reinterpret_cast<const f32x4*>(src + 4);
+                    }
+#pragma unroll
+                for (int p = 0; p < kArMaxWorld; ++p)
+                    if (p < a.world) {
+                        x0 += w0[p];
+                        x1 += w1[p];
+                    }
                 float* r = reinterpret_cast<float*>(red) + i * 8;
                 *reinterpret_cast<f32x4*>(r) = x0;
                 *reinterpret_cast<f32x4*>(r + 4) = x1;
@@ -195,35 +204,42 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(const ArArgs a) {
     }
     if (!ok1 && tid == 0) __hip_atomic_store(status_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- shot 2: gather every peer's reduced slice ----------------------------------------------------------
-    for (int q = 1; q < a.world; ++q) {
-        const int p = (a.rank + q) % a.world;  // start with a different peer on every rank: all links busy
+    // The peers are dealt over the workgroups (the launch's grid is a multiple of world - 1): all of a rank's inbound
+    // links carry data at the same time, and a workgroup waits for ITS peer only.  A lane keeps kGather 16-byte loads in
+    // flight before its first store: grid x 256 lanes x 16 B x kGather per rank (Little's law against the
+    // ~3 us a remote read takes).
+    if (a.world > 1) {
+        constexpr int kGather = 8;
+        const int npeer = a.world - 1;
+        const int q = 1 + (int)(blockIdx.x % npeer);
+        const int p = (a.rank + q) % a.world;  // a different first peer on every rank
         if (tid == 0) s_ok = wait_flag(flag_ptr(mine, 1, p), epoch, a.spin_limit) ? 1u : 0u;
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         const bool ok2 = s_ok != 0;
         if (!ok2 && tid == 0) __hip_atomic_store(status_w, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t p0 = (int64_t)p * a.slice, p1 = a.count < p0 + a.slice ? a.count : p0 + a.slice;
-        const int64_t nv = p1 > p0 ? (p1 - p0 + 7) / 8 : 0;
+        const int64_t nbytes = p1 > p0 ? (p1 - p0) * E : 0;  // the slice starts 16-byte aligned (slice % 8 == 0)
+        const int64_t n16 = nbytes / 16;
         const char* src = a.block[p] + kArHeaderPad + a.stage_bytes;
+        char* dst = static_cast<char*>(a.out) + p0 * E;
         if (ok2) {
-            for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < nv; i += (int64_t)gridDim.x * 256) {
-                const int64_t e0 = p0 + i * 8;
-                if (e0 + 8 <= a.count) {
-                    if (E == 4) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + e0) = *reinterpret_cast<const f32x4*>(src + i * 32);
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + e0 + 4) = *reinterpret_cast<const f32x4*>(src + i * 32 + 16);
-                    } else {
-                        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(a.out) + e0) = *reinterpret_cast<const u32x4*>(src + i * 16);
-                    }
-                } else {
-                    for (int j = 0; e0 + j < a.count; ++j) {
-                        if (E == 4) static_cast<float*>(a.out)[e0 + j] = reinterpret_cast<const float*>(src)[i * 8 + j];
-                        else static_cast<uint16_t*>(a.out)[e0 + j] = reinterpret_cast<const uint16_t*>(src)[i * 8 + j];
-                    }
+            const int64_t lanes = (int64_t)((gridDim.x - (q - 1) + npeer - 1) / npeer) * 256;  // lanes serving this peer
+            for (int64_t i = (int64_t)(blockIdx.x / npeer) * 256 + tid; i < n16; i += lanes * kGather) {
+                u32x4 v[kGather];
+#pragma unroll
+                for (int u = 0; u < kGather; ++u) {
+                    const int64_t j = i + u * lanes;
+                    v[u] = *reinterpret_cast<const u32x4*>(src + (j < n16 ? j : n16 - 1) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < kGather; ++u) {
+                    const int64_t j = i + u * lanes;
+                    if (j < n16) *reinterpret_cast<u32x4*>(dst + j * 16) = v[u];
                 }
             }
+            if (blockIdx.x / npeer == 0 && tid < (nbytes & 15)) dst[n16 * 16 + tid] = src[n16 * 16 + tid];  // count % 8 elements
         }
-        __syncthreads();
     }
 }
 
@@ -253,9 +269,12 @@ int launch_allreduce(char* const* blocks, size_t block_bytes, const void* in, vo
     a.spin_limit = 1u << (timeout_log2_polls > 0 ? timeout_log2_polls : kArSpinLog2Default);
     (void)block_bytes;
     const size_t bytes = (size_t)count * elt;
-    // few workgroups on purpose: the kernel waits on its peers, so every workgroup must be resident while it spins
-    // (also when several ranks share one device, as in the single-GPU test); 16 B per lane per step keeps the links busy
-    const int grid = (int)(bytes >= (8u << 20) ? 64 : bytes >= (1u << 20) ? 32 : 8);
+    // The kernel waits on its peers, so every workgroup must be resident while it spins -- also when all 8 ranks share
+    // one device, as in the single-GPU tests: 8 x 133 four-wave workgroups of <= 64 registers are half of what 256 CUs hold.
+    // A multiple of world - 1: shot 2 deals the peers over the workgroups.
+    const int want = (int)(bytes >= (8u << 20) ? 128 : bytes >= (1u << 20) ? 32 : 8);
+    const int npeer = world > 1 ? world - 1 : 1;
+    const int grid = (want + npeer - 1) / npeer * npeer;
     hipLaunchKernelGGL(ar_stage_kernel, dim3(grid), dim3(256), 0, s, a, elt);
     if (dtype == HYD_F32) hipLaunchKernelGGL((ar_reduce_kernel<float>), dim3(grid), dim3(256), 0, s, a);
     else if (dtype == HYD_BF16) hipLaunchKernelGGL((ar_reduce_kernel<BF16>), dim3(grid), dim3(256), 0, s, a);

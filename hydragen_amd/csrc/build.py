@@ -44,21 +44,12 @@ def _stale(target: Path, deps) -> bool:
     return any((HERE / d).stat().st_mtime > t for d in deps)
 
 
-def _compile(src: str, force: bool) -> Path:
-    obj = HERE / (Path(src).stem + ".o")
-    if force or _stale(obj, [src] + _includes(src) + ["build.py"]):
-        cmd = [HIPCC, *FLAGS, "-c", str(HERE / src), "-o", str(obj)]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
-    return obj
-
-
 # The prefix kernels keep O and Q in literal registers that only their asm statements name (prefix_unit_w64.h); whether
 # hipcc stays out of them is a property of the compiler release, so it is checked on the assembly of every (re)compile
-# (regcheck.py).  A failed check leaves no object, no stamp and no library behind: nothing loads, nothing computes wrongly.
+# (regcheck.py) -- the assembly OF THE OBJECT THAT IS LINKED: these sources are compiled with -save-temps=obj into a scratch
+# directory, the device assembly of that very compile (same flags, -fPIC and -Werror included) is checked, and only then is
+# the object moved into place.  A failed check leaves no object, no stamp and no library behind: nothing loads, nothing
+# computes wrongly.
 REGCHECKED = ["prefix_attn_w64.hip", "prefix_attn_w64_f16.hip"]
 
 
@@ -66,31 +57,52 @@ def _stamp(src: str) -> Path:
     return HERE / (Path(src).stem + ".regcheck")
 
 
-def _regcheck(src: str, force: bool) -> None:
+def _compile(src: str, force: bool) -> Path:
+    obj = HERE / (Path(src).stem + ".o")
+    checked = src in REGCHECKED
+    deps = [src] + _includes(src) + ["build.py"]
+    stale = force or _stale(obj, deps) or (checked and _stale(_stamp(src), deps + ["regcheck.py"]))
+    if not stale:
+        return obj
+    if not checked:
+        cmd = [HIPCC, *FLAGS, "-c", str(HERE / src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+    import shutil
+    import tempfile
+
     from regcheck import check_prefix_asm  # (build.py runs as a script and as hydragen_amd.csrc.build: plain import by path)
 
-    stamp = _stamp(src)
-    if not (force or _stale(stamp, [src] + _includes(src) + ["build.py", "regcheck.py"])):
-        return
-    stamp.unlink(missing_ok=True)
-    cmd = [HIPCC, *[f for f in FLAGS if f not in ("-fPIC", "-Werror")], "-S", "--cuda-device-only", str(HERE / src), "-o", "-"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
-    check_prefix_asm(r.stdout, src)
-    ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()
-    stamp.write_text("registers checked: " + (ver[0] if ver else "hipcc") + "\n")
+    _stamp(src).unlink(missing_ok=True)
+    obj.unlink(missing_ok=True)
+    tmp = Path(tempfile.mkdtemp(prefix="hyd_regcheck_"))
+    try:
+        tobj = tmp / obj.name
+        r = subprocess.run([HIPCC, *FLAGS, "-save-temps=obj", "-c", str(HERE / src), "-o", str(tobj)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        asm = sorted(tmp.glob(Path(src).stem + "-hip-amdgcn-amd-amdhsa-gfx950*.s"))
+        if len(asm) != 1:
+            raise RuntimeError(f"{src}: expected one device assembly file from -save-temps, found {[a.name for a in asm]}")
+        check_prefix_asm(asm[0].read_text(), src)
+        shutil.move(str(tobj), str(obj))
+        ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()
+        _stamp(src).write_text("registers checked on the linked object's own assembly: " + (ver[0] if ver else "hipcc") + "\n")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return obj
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     if str(HERE) not in sys.path:
         sys.path.insert(0, str(HERE))
     with ThreadPoolExecutor(max_workers=6) as ex:
-        checks = [ex.submit(_regcheck, s, force) for s in REGCHECKED]
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
         try:
-            for c in checks:
-                c.result()
+            objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
         except Exception:
             for s in REGCHECKED:  # nothing built from these sources may survive
                 (HERE / (Path(s).stem + ".o")).unlink(missing_ok=True)

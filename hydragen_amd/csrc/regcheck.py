@@ -79,8 +79,8 @@ def check_prefix_asm(asm: str, what: str = "prefix kernels") -> None:
             raise RegisterOwnershipError(f"{what}: {k['name']} spills ({k['spill']} VGPRs, {k['scratch']} bytes of scratch)")
         if "w64x8" in k["name"] and (k["agpr"] != 0 or k["vgpr"] != 256):
             raise RegisterOwnershipError(f"{what}: {k['name']} must allocate 256 VGPRs and no AGPR, has {k['vgpr']} / {k['agpr']}")
-        if "prefix_attn_w64_kernel" in k["name"] and k["agpr"] < 160:
-            raise RegisterOwnershipError(f"{what}: {k['name']} allocates {k['agpr']} AGPRs (< 160: a[0:191] are the unit's)")
+        if "prefix_attn_w64_kernel" in k["name"] and k["agpr"] < 192:
+            raise RegisterOwnershipError(f"{what}: {k['name']} allocates {k['agpr']} AGPRs (< 192: the unit's asm names a[0:191])")
     use = eight_wave_usage(asm)
     if not use:
         raise RegisterOwnershipError(f"{what}: no 8-wave kernel found")

@@ -115,14 +115,143 @@ __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, i
     if (hvalid) finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
 }
 
+// Token-row form of the one-query-row decode shape (nq == 1, Hq == Hkv, D = 128 -- C2): a WORKGROUP walks the whole
+// token rows of one sequence, 16 * NI kv heads x 256 B = NI KB contiguous per wave, the workgroup's four waves side by
+// side.  A lane group of 16 lanes owns NI heads outright (all of their keys arrive in the same lanes): no merge across
+// lane groups or waves at the end, one eighth of the waves (and of the wave starts, page touches and epilogues) of the
+// one-unit-per-wave form, and every tensor of a sequence is read as ONE contiguous run (S x Hkv x 256 B) by one
+// workgroup instead of as 1 KB pieces by eight workgroups at different times.  Two buffers of UT tokens per wave: chunk
+// c + 1 is requested before chunk c is consumed, so a wave always has bytes in flight.
+template <typename T, int NI, int UT, int DB, int NPRE>
+__global__ __launch_bounds__(256, (NI * UT * (1 + DB) > 8 ? 2 : NI * UT * (1 + DB) > 4 ? 3 : 4)) void suffix_rows_kernel(const SuffixArgs a) {
+    using TR = Traits<T>;
+    constexpr int D = 128, LPK = 16, HPI = 4;  // lanes per head row, heads per wave instruction
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane % LPK, hg = lane / LPK;
+    const int b = blockIdx.x;
+    const int h0 = (blockIdx.y * 4 + wave) * (HPI * NI);  // first head of this wave
+    if (h0 >= a.Hkv) return;
+
+    int len = a.kv_len;
+    if (a.sl32) len = a.sl32[b];
+    else if (a.sl64) len = (int)a.sl64[b];
+    len = max(0, min(len, a.kv_len));
+
+    int64_t ridx[NI];
+    u32x4 qp[NI];
+    PrePartials<NPRE> pp[NI];
+    const int npre = min(n_prefetched(a), NPRE);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        ridx[i] = (int64_t)b * a.Hq + h0 + i * HPI + hg;  // nq == 1, g == 1: [B, 1, Hq]
+        qp[i] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.q) + ridx[i] * D + sub * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) prefetch_partials(a, npre, ridx[i], sub, D, pp[i]);
+
+    const gchar_p kbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)h0 * a.k_hs));
+    const gchar_p vbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)h0 * a.v_hs));
+    const unsigned klane = (unsigned)(hg * a.k_hs * 2 + sub * 16), vlane = (unsigned)(hg * a.v_hs * 2 + sub * 16);
+    const unsigned kis = (unsigned)(HPI * a.k_hs * 2), vis = (unsigned)(HPI * a.v_hs * 2);  // bytes between a wave's instructions
+    const unsigned krs = (unsigned)(a.k_ts * 2), vrs = (unsigned)(a.v_ts * 2);              // token stride in bytes
+
+    float m[NI], l[NI], acc[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        m[i] = -INFINITY;
+        l[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    }
+    const float sc = a.scale_log2e;
+
+    struct Buf {
+        u32x4 k[UT][NI], v[UT][NI];
+    };
+    auto issue = [&](Buf& bf, int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const unsigned tc = (unsigned)min(t0 + u, len - 1);  // never predicate a load: clamp, the score is masked
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                bf.k[u][i] = __builtin_nontemporal_load((gu32x4_p)(kbu + (tc * krs + i * kis + klane)));
+                bf.v[u][i] = __builtin_nontemporal_load((gu32x4_p)(vbu + (tc * vrs + i * vis + vlane)));
+            }
+        }
+    };
+    auto consume = [&](const Buf& bf, int t0, auto MASKED) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float sv[UT];
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d = TR::dot2(qp[i][e], bf.k[u][i][e], d);
+                d = group_sum<LPK>(d) * sc;
+                sv[u] = (!decltype(MASKED)::value || t0 + u < len) ? d : -INFINITY;  // wave-uniform condition
+            }
+            float cmax = sv[0];
+#pragma unroll
+            for (int u = 1; u < UT; ++u) cmax = fmaxf(cmax, sv[u]);
+            const float mnew = fmaxf(m[i], cmax);  // finite: t0 < len
+            const float alpha = fast_exp2(m[i] - mnew);
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                sv[u] = fast_exp2(sv[u] - mnew);
+                ps += sv[u];
+            }
+            l[i] = l[i] * alpha + ps;
+            m[i] = mnew;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] *= alpha;
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                float vf[8];
+                widen8<T>(bf.v[u][i], vf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_fmaf(sv[u], vf[j], acc[i][j]);
+            }
+        }
+    };
+    using Full = std::integral_constant<bool, false>;
+    using Masked = std::integral_constant<bool, true>;
+    const int nfull = len / UT;
+    Buf A, Bb;
+    if constexpr (DB == 0) {
+        for (int c = 0; c < nfull; ++c) {
+            issue(A, c * UT);
+            consume(A, c * UT, Full{});
+        }
+    } else if (nfull > 0) {
+        issue(A, 0);
+        int c = 0;
+        for (; c + 2 <= nfull; c += 2) {
+            issue(Bb, (c + 1) * UT);
+            consume(A, c * UT, Full{});
+            if (c + 2 < nfull) issue(A, (c + 2) * UT);
+            consume(Bb, (c + 1) * UT, Full{});
+        }
+        if (c < nfull) consume(A, c * UT, Full{});
+    }
+    if (nfull * UT < len) {
+        issue(A, nfull * UT);
+        consume(A, nfull * UT, Masked{});
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) finish_row<T, D, 2, NPRE>(a, ridx[i], sub, m[i], l[i], acc[i], npre, pp[i]);
+}
+
 // NPRE: 16-bit partials fetched under the K/V stream (suffix_common.h); 2 is instantiated for the decode shape only
 // (R = 1, one wave per unit) and launched when the call has two such partials (a two-level hierarchy).
-template <typename T, int D, int R, int WPU, int NPRE = 1>
-__global__ __launch_bounds__(256, (R == 1 ? 6 : 1)) void suffix_attn_kernel(const SuffixArgs a) {
+template <typename T, int D, int R, int WPU, int NPRE = 1, int U_ = 4, int OCC = (R == 1 ? 6 : 1)>
+__global__ __launch_bounds__(256, OCC) void suffix_attn_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int LPK = D / 8;    // lanes per key row
     constexpr int KPI = 64 / LPK; // keys per wave instruction
-    constexpr int U = 4;  // key iterations in flight per wave (x2 tensors x 1 KiB); occupancy supplies the rest
+    constexpr int U = U_;  // key iterations in flight per wave (x2 tensors x 1 KiB); occupancy supplies the rest
     __shared__ float xbuf[WPU > 1 ? (WPU - 1) * R * (2 + D) : 1];
 
     const int tid = threadIdx.x;
@@ -326,6 +455,36 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
         if (const char* e = getenv("HYD_ANYORDER"); e && atoi(e)) {
             hipExtLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, a);
             return (int)hipGetLastError();
+        }
+        // token-row form A/B: HYD_SUFFIX_ROWS = <NI><UT><DB>
+        if constexpr (R == 1 && D == 128) {
+            if (const char* e = getenv("HYD_SUFFIX_ROWS"); e && atoi(e) && a.packed && a.n_pre < 2) {
+                const int v = atoi(e), ni = v / 100;
+                if (a.Hkv % (4 * ni) == 0) {
+                    dim3 g2(a.B, (a.Hkv + 16 * ni - 1) / (16 * ni), 1);
+                    switch (v) {
+#define HYD_ROWS_CASE(NI_, UT_, DB_) \
+    case NI_ * 100 + UT_ * 10 + DB_: hipLaunchKernelGGL((suffix_rows_kernel<T, NI_, UT_, DB_, 1>), g2, dim3(256), 0, s, a); return (int)hipGetLastError();
+                        HYD_ROWS_CASE(1, 2, 1) HYD_ROWS_CASE(1, 4, 1) HYD_ROWS_CASE(1, 4, 0) HYD_ROWS_CASE(1, 8, 0)
+                        HYD_ROWS_CASE(2, 1, 1) HYD_ROWS_CASE(2, 2, 0) HYD_ROWS_CASE(2, 2, 1) HYD_ROWS_CASE(2, 4, 0)
+#undef HYD_ROWS_CASE
+                        default: break;
+                    }
+                }
+            }
+        }
+        // occupancy A/B (VERDICT r5 next #1c): key iterations in flight x resident waves per SIMD
+        if constexpr (R == 1 && D == 128) {
+            if (const char* e = getenv("HYD_SUFFIX_OCC"); e && a.n_pre < 2) {
+                switch (atoi(e)) {
+                    case 48: hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 1, 4, 8>), grid, dim3(256), 0, s, a); return (int)hipGetLastError();
+                    case 38: hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 1, 3, 8>), grid, dim3(256), 0, s, a); return (int)hipGetLastError();
+                    case 28: hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 1, 2, 8>), grid, dim3(256), 0, s, a); return (int)hipGetLastError();
+                    case 65: hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 1, 6, 5>), grid, dim3(256), 0, s, a); return (int)hipGetLastError();
+                    case 84: hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 1, 8, 4>), grid, dim3(256), 0, s, a); return (int)hipGetLastError();
+                    default: break;
+                }
+            }
         }
 #endif
         if constexpr (R == 1) {

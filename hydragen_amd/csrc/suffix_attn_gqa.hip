@@ -445,11 +445,23 @@ bool suffix_gqa_eligible(const SuffixArgs& a, int D, bool any_shape) {
 template <typename T, int D, int WPU, bool NT, int HPW>
 static int launch_gqa_k(const SuffixArgs& a, dim3 grid, size_t pad, hipStream_t s) {
     constexpr int NWV = WPU * HPW;
-    constexpr size_t lds = (size_t)NWV * 2 * 32 * D * 2 + (size_t)NWV * 4 * 16 * sizeof(float);
+    // the K/V landing tiles, plus the (m, l) exchange area that only the cross-wave merge of WPU > 1 touches: one-wave units ask
+    // for the tiles alone, which is at most 64 KB for every shape picked from shapes (HPW = 4 at D = 128, HPW = 2 at D = 256)
+    constexpr size_t lds = (size_t)NWV * 2 * 32 * D * 2 + (WPU > 1 ? (size_t)NWV * 4 * 16 * sizeof(float) : 0);
     auto kern = suffix_attn_gqa_kernel<T, D, WPU, NT, HPW>;
-    // once per instantiation, thread-safe (C++11 static initialisation)
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (attr_rc != hipSuccess) return (int)attr_rc;
+    if (lds + pad > 64 * 1024) {
+        // more than the default dynamic-LDS limit (four-wave units; development pads): raise it, once per DEVICE and instantiation --
+        // the attribute belongs to the function as loaded on the current device, and a process may launch on several
+        static hipError_t attr_rc[16];
+        static bool attr_set[16];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+        if (!__atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {  // idempotent: two threads racing both set the same value
+            attr_rc[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            __atomic_store_n(&attr_set[dev], true, __ATOMIC_RELEASE);
+        }
+        if (attr_rc[dev] != hipSuccess) return (int)attr_rc[dev];
+    }
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds + pad, s, a);
     return (int)hipGetLastError();
 }

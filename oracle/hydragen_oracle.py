@@ -38,8 +38,12 @@ def _f64(x):
     return np.asarray(x, dtype=np.float64)
 
 
-def attention_lse(q, k, v, causal: bool = False, kv_lens=None):
+def attention_lse(q, k, v, causal: bool = False, kv_lens=None, round_p=None):
     """Exact softmax attention returning (out, lse).
+
+    round_p (callable or None): the reference's kernels round the un-normalised probabilities to the q dtype
+    before P.V while the row sum keeps the un-rounded ones (xformers_stuff.py:388-391; flash-attn v2.3.6 does
+    the same in its softmax -> P.V step).  Pass round_bf16 / round_fp16 to model that; None = exact.
 
     q [b, sq, hq, d]; k, v [b, sk, hkv, d]; GQA: q-head h reads kv-head h // (hq//hkv).
     scale = d**-0.5 (flash.py:293); lse = natural-log logsumexp of the scaled
@@ -72,8 +76,9 @@ def attention_lse(q, k, v, causal: bool = False, kv_lens=None):
             m = np.where(np.isfinite(m), m, 0.0)
             p = np.exp(s - m)
             l = p.sum(axis=1, keepdims=True)
+            pr = p if round_p is None else round_p(p)
             with np.errstate(divide="ignore", invalid="ignore"):
-                o = np.where(l > 0, (p @ vv) / l, 0.0)
+                o = np.where(l > 0, (pr @ vv) / l, 0.0)
                 ls = np.where(l[:, 0] > 0, m[:, 0] + np.log(l[:, 0]), NEG_INF)
             out[bi, :, h] = o
             lse[bi, h] = ls
@@ -101,7 +106,7 @@ def flash_attention(q, k, v, causal: bool = False):
     return attention_lse(q, k, v, causal=causal)
 
 
-def flash_attention_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False):
+def flash_attention_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, round_p=None):
     """flash.py:309-351 -- packed q [sum_q, hq, d], k/v [sum_k, hkv, d].
 
     Returns out [sum_q, hq, d] and lse [nseq, hq, max_seqlen_q] (flash-attn 2.3.6
@@ -116,18 +121,18 @@ def flash_attention_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
     for i in range(nseq):
         q0, q1 = int(cu_seqlens_q[i]), int(cu_seqlens_q[i + 1])
         k0, k1 = int(cu_seqlens_k[i]), int(cu_seqlens_k[i + 1])
-        o, l = attention_lse(q[None, q0:q1], k[None, k0:k1], v[None, k0:k1], causal=causal)
+        o, l = attention_lse(q[None, q0:q1], k[None, k0:k1], v[None, k0:k1], causal=causal, round_p=round_p)
         out[q0:q1] = o[0]
         lse[i, :, : q1 - q0] = l[0]
     return out, lse
 
 
-def flash_attention_seqlen(q, k, v, seq_len):
+def flash_attention_seqlen(q, k, v, seq_len, round_p=None):
     """flash.py:163-281 -- non-causal attention of every query row over the first
     seq_len[b] keys of sequence b.  Returns (out [b,q,h,d], lse [b,q,h]) with the
     natural-log LSE that flash.py:159-160 writes.
     """
-    out, lse = attention_lse(q, k, v, causal=False, kv_lens=seq_len)
+    out, lse = attention_lse(q, k, v, causal=False, kv_lens=seq_len, round_p=round_p)
     return out, np.transpose(lse, (0, 2, 1))
 
 
@@ -142,8 +147,12 @@ def hydragen_attention(
     use_varlens,
     seq_lens=None,
     round_partials=None,
+    round_p=None,
 ):
     """attention.py:177-354.
+
+    `round_p`: see attention_lse.  round_partials = round_p = round_bf16 and a final round_bf16 of the result is
+    the REFERENCE'S OWN ARITHMETIC in float64 ("reference rounding model", reference_rounding_model below).
 
     Sequence i of the batch belongs to shared sequence i // (B / sb) at every
     level (attention.py:264-268).  `round_partials` (callable or None) is applied
@@ -163,7 +172,7 @@ def hydragen_attention(
             ns = sk.shape[0]
             assert b % ns == 0
             batched_q = q.reshape(ns, (b // ns) * nq, hq, d)  # attention.py:264-268
-            so, sl = attention_lse(batched_q, sk, sv)
+            so, sl = attention_lse(batched_q, sk, sv, round_p=round_p)
             so = so.reshape(b, nq, hq, d)
             if k.shape[1] == 0 and len(shared_ks) == 1:  # attention.py:273-274
                 return so
@@ -174,7 +183,7 @@ def hydragen_attention(
             assert b % ns == 0
             qps = (b // ns) * nq
             cu_q = np.arange(ns + 1) * qps  # attention.py:295-311
-            so, sl = flash_attention_varlen(q.reshape(b * nq, hq, d), sk, sv, cu_q, scu, qps, smax)
+            so, sl = flash_attention_varlen(q.reshape(b * nq, hq, d), sk, sv, cu_q, scu, qps, smax, round_p=round_p)
             so = so.reshape(b, nq, hq, d)
             if k.shape[1] == 0 and len(shared_ks) == 1:
                 return so
@@ -183,21 +192,33 @@ def hydragen_attention(
         lses.append(sl)
 
     if seq_lens is None:
-        uo, ul = attention_lse(q, k, v, causal=True)  # attention.py:344-345
+        uo, ul = attention_lse(q, k, v, causal=True, round_p=round_p)  # attention.py:344-345
         ul = np.transpose(ul, (0, 2, 1))
     else:
-        uo, ul = flash_attention_seqlen(q, k, v, seq_lens)  # attention.py:347
+        uo, ul = flash_attention_seqlen(q, k, v, seq_lens, round_p=round_p)  # attention.py:347
     outs.append(rp(uo))
     lses.append(ul)
     return combine_lse(outs, lses)
 
 
-def hydragen_attention_nopad(q, k, v, shared_ks, shared_vs, seq_len=None, round_partials=None):
+def hydragen_attention_nopad(q, k, v, shared_ks, shared_vs, seq_len=None, round_partials=None, round_p=None):
     """attention.py:357-392."""
     n = len(shared_ks)
     return hydragen_attention(
-        q, k, v, shared_ks, shared_vs, [None] * n, [None] * n, [False] * n, seq_len, round_partials
+        q, k, v, shared_ks, shared_vs, [None] * n, [None] * n, [False] * n, seq_len, round_partials, round_p
     )
+
+
+def reference_rounding_model(dtype: str, q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens, use_varlens,
+                             seq_lens=None):
+    """The reference's OWN roundings, everything else float64: probabilities rounded to the q dtype before P.V
+    (xformers_stuff.py:391; flash-attn), every partial `out` rounded to the q dtype on its way through HBM
+    (attention.py:272, flash.py:254 -- the precision loss README.md:488-490 acknowledges), the merged result
+    rounded to the q dtype (attention.py:120,147).  Its distance from the exact answer is the error the reference
+    itself makes on these inputs: the yardstick of tests/test_reference_error_budget_gpu.py."""
+    rnd = round_bf16 if dtype == "bf16" else round_fp16
+    return rnd(hydragen_attention(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_seq_lens, use_varlens,
+                                  seq_lens, round_partials=rnd, round_p=rnd))
 
 
 def nosharing_attention(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, use_varlens, seq_lens=None):

@@ -20,11 +20,16 @@ def _worker(rank, world, port, ret):
 
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        comm = XgmiAllReduce(max_bytes=9 << 20)
+        comm = XgmiAllReduce(max_bytes=(33 << 20) if world > 2 else (9 << 20))
         worst = 0.0
         cases = [(torch.bfloat16, 1024 * 4096), (torch.float16, 4097), (torch.float32, 1000003), (torch.bfloat16, 8),
                  (torch.bfloat16, 7), (torch.float16, 2 * 1024 * 1024 + 24)]
-        for rep in range(3):  # repeated calls: epochs, flag reuse, staging reuse
+        if world > 2:
+            # the 8-slice exchange of the C5 message (32 MiB bf16: [2048, 1, 8192], tp.py:108-112), counts below world x 8
+            # (empty slices), odd counts (a ragged last slice), fp32 at a size where every workgroup of shot 2 has work
+            cases += [(torch.bfloat16, 2048 * 8192), (torch.bfloat16, world * 8 - 3), (torch.float16, world + 1),
+                      (torch.float32, 3), (torch.bfloat16, 8 * 1024 * 1024 + 13), (torch.float32, 4 * 1024 * 1024 + 5)]
+        for rep in range(3 if world <= 2 else 2):  # repeated calls: epochs, flag reuse, staging reuse
             for dt, n in cases:
                 g = torch.Generator(device="cuda").manual_seed(100 * rep + n % 997 + rank)
                 x = torch.randn(n, device="cuda", dtype=dt, generator=g)
@@ -75,16 +80,20 @@ def _worker(rank, world, port, ret):
         ret.put((rank, "fail", traceback.format_exc()))
 
 
-def test_xgmi_allreduce_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_xgmi_allreduce_ranks_on_one_gpu(world):
+    """world = 4 and 8 rehearse what a real node runs (tp.py:115-132; the reference's sweeps use --nproc_per_node=8,
+    docs/sweeps_from_paper.md:25-150): the 8-slice two-shot exchange, peers dealt over the workgroups of shot 2, every
+    rank's workgroups co-resident on the one device while they wait for each other."""
     import torch.multiprocessing as mp
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [ret.get(timeout=240) for _ in procs]
+    res = [ret.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(60)
     for rank, state, info in res:

@@ -112,6 +112,32 @@ def test_bench_c5_workload_on_two_ranks():
     assert res["roofline"]["bound"] in ("hbm", "mfma") and 0 < res["roofline"]["frac"] < 1
 
 
+@pytest.mark.gpu
+def test_bench_c5_workload_on_eight_ranks():
+    """What `--gpus 8 --workload c5` executes on a real node (the reference's sweeps run --nproc_per_node=8,
+    docs/sweeps_from_paper.md:25-150; sharding tp.py:115-132), rehearsed with eight processes on the one device: the
+    Hkv / N = 1 rank shape (8 q / 1 kv head per rank), an 8-process pre-flight -- every stage, incl. one `hyd_allreduce_sum`
+    over eight hipIpc-mapped blocks -- and the xGMI leg's 8-slice exchange of the step's [B, 1, 8192] block output.  Batch
+    reduced to 256 so that eight shards and eight contexts share one GPU comfortably; everything else is the preset's."""
+    env = dict(os.environ, HYD_BENCH_BACKEND="gloo", HYD_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--workload", "c5", "--gpus", "8", "--batch", "256", "--steps", "8",
+                        "--warmup", "2", "--trials", "0", "--no-cpu-baseline", "--no-accuracy"],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=str(REPO))
+    assert r.returncode == 0, r.stderr[-3000:]
+    stages = [json.loads(ln[len("[preflight] "):]) for ln in r.stdout.splitlines() if ln.startswith("[preflight] ")]
+    assert [s_["stage"] for s_ in stages] == ["devices", "rccl_init", "peer_access", "xgmi_allreduce", "graph_collective", "agreement"]
+    assert all(s_["ok"] for s_ in stages), stages
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["value"] > 0
+    assert cfg["preset"] == "c5" and cfg["batch"] == 256 and cfg["qheads"] == 64 and cfg["kvheads"] == 8
+    assert "TP8" in cfg["parallelism"].upper()
+    assert res["allreduce_bytes"] == 256 * 8192 * 2
+    assert res["allreduce_xgmi"]["max_abs_diff_vs_rccl"] < 0.5  # eight ranks' hyd_allreduce_sum agrees with the group's
+
+
 def test_workload_presets_and_overrides(monkeypatch):
     import bench
 
