@@ -55,7 +55,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-HBM_ACHIEVABLE_GBS = 6300.0  # measured streaming ceiling per /opt/skills/guides/MI355X_MICROARCH.md (79 % of spec)
+# (round 6: no "achievable" constant any more -- round 5's 6300 GB/s flattered the line, the same run streamed 6.8 TB/s elsewhere.
+#  roofline.achievable_peak is the best HBM rate MEASURED IN THIS RUN by an HBM-bound launch of this library: the no-sharing
+#  leg's suffix pass over [prefix + suffix] private keys per sequence, or the timed steps' own best suffix length.)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
 SWEEP = (16, 32, 48, 64, 80, 96, 112, 128)  # docs/sweeps_from_paper.md:159-161 restricted to C2's 0..128
 # BASELINE.json configs that bench.py runs as a workload (the others are parity-test cases: tests/test_fullsize_gpu.py)
@@ -377,15 +379,19 @@ def main():
     pre_tflops = pre_flops * n_ev / (sum(pre_ms) * 1e-3) / 1e12
     suffix_roof = {
         "kernel": ("suffix_attn_gqa_kernel (matrix-core suffix pass for grouped-query heads + fused LSE combine)" if args.qheads // args.kvheads >= 4
+                   else "suffix_attn_rows_kernel (token-row suffix pass + fused LSE combine)" if Hq == Hkv and Hkv % 4 == 0
                    else "suffix_attn_kernel (suffix pass + fused LSE combine)"),
         "bound": "hbm", "achieved": suf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": suf_gbs / HBM_PEAK_GBS, "traffic": None,
         "avg_launch_us": sum(suf_ms) / n_ev * 1e3,
         "algorithmic_bytes_per_launch_mean": sum(suf_bytes_of(s) for s in sched) / args.steps,
         "share_of_timed_region": sum(suf_ms) / (sum(suf_ms) + sum(pre_ms)),
-        # MI355X_MICROARCH.md: 8.0 TB/s is the spec; a float4 copy measures 6.29 TB/s, streaming reads 6.4-6.8 TB/s
-        "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": suf_gbs / HBM_ACHIEVABLE_GBS,
     }
+    # the best rate an HBM-bound launch of this library reached IN THIS RUN (so far: the timed steps' best suffix length; the
+    # no-sharing leg below replaces it when it streams faster) -- MI355X_MICROARCH.md: 8.0 TB/s is the spec
+    best_step = max(suf_bytes[i] / (suf_ms[i] * 1e-3) / 1e9 for i in range(n_ev))
+    suffix_roof.update(achievable_peak=best_step, achievable_peak_source="best timed step of this run (by its events)",
+                       frac_of_achievable=suf_gbs / best_step)
     prefix_roof = {
         "kernel": "prefix_attn kernel (batched-query MFMA pass over the shared prefix)",
         "bound": "mfma", "achieved": pre_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -474,6 +480,10 @@ def main():
         ns = res["reference_protocol"].get("nosharing_speedup_mean")
         if ns is not None:
             res["nosharing_speedup"] = ns
+        nsr = res["reference_protocol"].get("nosharing_GBs_at_max_suffix")
+        if nsr is not None and nsr > suffix_roof["achievable_peak"]:
+            suffix_roof.update(achievable_peak=nsr, frac_of_achievable=suffix_roof["achieved"] / nsr,
+                               achievable_peak_source="this run's no-sharing leg: the same library's suffix pass over prefix + suffix private keys per sequence")
     if rank == 0 and not args.no_accuracy:
         res["accuracy"] = accuracy(ops, q, sk, sv, k, v, S // 2)
     if solo and not args.no_paper_sweep:

@@ -111,8 +111,11 @@ int plan_prefix(const hyd_prefix_params* p, PrefixPlan* pl, int max_splits = kMa
             // profiles/r05_split_plan_sweep.txt (the consumer's epilogue pays for it in latency as well).  The minimum is at
             // ns = sqrt(kv_len c / s1): C3 16, a TP = 8 shard of C2 (4/4 heads) 4 instead of 8 (whole call 48.4 -> 43.4 us),
             // B = 64, 32/8 heads, P = 4096 8 instead of 16 (37.1 -> 30.9), B = 256, 32/32, P = 512 unsplit (67.2 -> 62.8).
+            // c is per key of a 128-row unit at D = 128; the loop's MFMAs per key (D / 16 for QK^T + D / 16 for PV) and the staged bytes
+            // scale with D, and so does a slice (s1): the optimum is the same split count at every head dim.
+            const double c_us = 0.0136 * (double)p->D / 128.0;
             const double s1_us = (double)p->B * p->nq * p->Hq * p->D * 16.0 / 5.0e6;
-            const double best = sqrt((double)p->kv_len * 0.0136 / s1_us);
+            const double best = sqrt((double)p->kv_len * c_us / s1_us);
             const int by_cost = best < 1.5 ? 1 : (int)(best + 0.5);
             if (by_cost < ns) ns = by_cost;
         }

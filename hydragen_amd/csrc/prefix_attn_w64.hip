@@ -10,7 +10,7 @@ int launch_prefix_w64(const PrefixArgs& a, int dtype, int D, bool causal, int gr
     if (a.dbg && dtype == HYD_BF16 && D == 128 && !causal && a.wg_rows == 128) {
         switch (a.dbg) {
 #define HYD_ABL(N) case N: return launch_prefix_w64_t<BF16, 128, false, 2, N>(a, grid, s);
-            HYD_ABL(1) HYD_ABL(4) HYD_ABL(5) HYD_ABL(8) HYD_ABL(32) HYD_ABL(64) HYD_ABL(65) HYD_ABL(128) HYD_ABL(2048) HYD_ABL(4096) HYD_ABL(2049) HYD_ABL(2052) HYD_ABL(2053) HYD_ABL(2056) HYD_ABL(2064)
+            HYD_ABL(1) HYD_ABL(4) HYD_ABL(5) HYD_ABL(8) HYD_ABL(32) HYD_ABL(64) HYD_ABL(65) HYD_ABL(128) HYD_ABL(2048) HYD_ABL(4096) HYD_ABL(2049) HYD_ABL(2052) HYD_ABL(2053) HYD_ABL(2056) HYD_ABL(2064) HYD_ABL(8192) HYD_ABL(16384) HYD_ABL(10240) HYD_ABL(18432)
 #undef HYD_ABL
             default: break;
         }

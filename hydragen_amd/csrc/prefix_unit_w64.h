@@ -848,6 +848,12 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
     else dma_wait_w<0>();
     __syncthreads();
     stampk(2);
+    // Static issue priority for one of the two waves that share a SIMD (MI355X_MICROARCH.md, "two waves per SIMD", item 4): waves w
+    // and w + 4 of a workgroup sit on the same SIMD; raised once in front of the key loop, no flips inside it.  Development
+    // builds: ABL bit 13 = the younger half (waves 4-7), bit 14 = the older half (A/B in profiles/r06_prefix_setprio.md).
+    if constexpr (NW == 8 && (ABL & (8192 | 16384)) != 0) {
+        if (((ABL & 8192) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+    }
     if (NB > 0) {
 #pragma unroll
         for (int c = 0; c < PDK; ++c) kfr[c] = ldk_at(c, slot_k(0));
@@ -905,6 +911,7 @@ __device__ __forceinline__ void prefix_unit_w64(const PrefixArgs& a, const int v
         __syncthreads();  // nothing in flight, everyone done with the rings before the merge reuses them
     }
     regs.drain();
+    if constexpr (NW == 8 && (ABL & (8192 | 16384)) != 0) __builtin_amdgcn_s_setprio(0);
     stampk(3);
 #undef HYD_IC
 

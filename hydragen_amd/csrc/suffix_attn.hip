@@ -115,133 +115,148 @@ __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, i
     if (hvalid) finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
 }
 
-// Token-row form of the one-query-row decode shape (nq == 1, Hq == Hkv, D = 128 -- C2): a WORKGROUP walks the whole
-// token rows of one sequence, 16 * NI kv heads x 256 B = NI KB contiguous per wave, the workgroup's four waves side by
-// side.  A lane group of 16 lanes owns NI heads outright (all of their keys arrive in the same lanes): no merge across
-// lane groups or waves at the end, one eighth of the waves (and of the wave starts, page touches and epilogues) of the
-// one-unit-per-wave form, and every tensor of a sequence is read as ONE contiguous run (S x Hkv x 256 B) by one
-// workgroup instead of as 1 KB pieces by eight workgroups at different times.  Two buffers of UT tokens per wave: chunk
-// c + 1 is requested before chunk c is consumed, so a wave always has bytes in flight.
-template <typename T, int NI, int UT, int DB, int NPRE>
-__global__ __launch_bounds__(256, (NI * UT * (1 + DB) > 8 ? 2 : NI * UT * (1 + DB) > 4 ? 3 : 4)) void suffix_rows_kernel(const SuffixArgs a) {
+// Token-row form of the one-query-row decode shape (nq == 1, Hq == Hkv, Hkv a multiple of the 64 / (D / 8) heads one wave
+// instruction covers -- C2 and its tensor-parallel shards): a wave walks the token rows of ONE sequence for HPI neighbouring
+// heads.  A lane group of D / 8 lanes owns one head outright (all of its keys arrive in the same lanes): one wave instruction
+// fetches 1 KB contiguous, the waves of a workgroup sit side by side on the token row (4 KB contiguous per token and tensor),
+// UT tokens x 2 tensors (16 KB at UT = 8) in flight per wave.  No merge across lane groups or waves at the end, and a quarter
+// of the waves (wave starts, page touches, epilogues, q / partial / output rows of 256 B) of the one-unit-per-wave kernel
+// below, which splits the keys of ONE head over a wave's four lane groups.
+// Measured at C2 (profiles/r06_suffix_rows_*.txt; same box, same arena, alternating): 165 vs 173 us at S = 64, 318 vs 337 at
+// S = 128, 87.6 vs 90.8 at S = 32, equal at S <= 16; UT = 8 beats 4 / 12 / 16, two heads per lane group, a second buffer,
+// eight-wave workgroups and head-major launch order all measured equal or worse.
+// ROT (development builds only): the full chunks of a sequence are walked from a per-sequence starting chunk (softmax does not
+// care about the order), so that workgroups that start together do not touch the same token offsets of caches that sit a
+// pathological distance apart.  Measured (profiles/r06_suffix_stride_sweep.txt): it rescues the bad strides (129 rows between
+// sequences: 193 vs 212 us at S = 64, the one-unit-per-wave kernel 243) and costs 2-10 % on the good ones (128 / 256 / 512 / 2048
+// rows, S = 128: 345 vs 332, 350 vs 318), which are the ones cache allocations have (capacities are multiples of 16 rows): not shipped.
+// Shapes with fewer than 4 waves per sequence put 4 / wps sequences into one workgroup (a.rows_wps_log2).
+template <typename T, int D, int UT, int NPRE, int ROT>
+__global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
-    constexpr int D = 128, LPK = 16, HPI = 4;  // lanes per head row, heads per wave instruction
+    constexpr int LPK = D / 8, HPI = 64 / LPK;  // lanes per head row, heads per wave instruction
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane % LPK, hg = lane / LPK;
-    const int b = blockIdx.x;
-    const int h0 = (blockIdx.y * 4 + wave) * (HPI * NI);  // first head of this wave
-    if (h0 >= a.Hkv) return;
+    // waves per sequence inside a workgroup: 4 (then blockIdx.y walks further head slices), 2 or 1
+    const int wl = a.rows_wps_log2;
+    const int b = (int)(blockIdx.x << (2 - wl)) + (wave >> wl);
+    const int h0 = (int)((blockIdx.y << wl) + (wave & ((1 << wl) - 1))) * HPI;  // first head of this wave
+    if (b >= a.B || h0 >= a.Hkv) return;
 
     int len = a.kv_len;
     if (a.sl32) len = a.sl32[b];
     else if (a.sl64) len = (int)a.sl64[b];
     len = max(0, min(len, a.kv_len));
 
-    int64_t ridx[NI];
-    u32x4 qp[NI];
-    PrePartials<NPRE> pp[NI];
+    const int64_t ridx = (int64_t)b * a.Hq + h0 + hg;  // nq == 1, g == 1: [B, 1, Hq]
+    const u32x4 qp = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.q) + ridx * D + sub * 8);
+    PrePartials<NPRE> pp;
     const int npre = min(n_prefetched(a), NPRE);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        ridx[i] = (int64_t)b * a.Hq + h0 + i * HPI + hg;  // nq == 1, g == 1: [B, 1, Hq]
-        qp[i] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.q) + ridx[i] * D + sub * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) prefetch_partials(a, npre, ridx[i], sub, D, pp[i]);
+    prefetch_partials(a, npre, ridx, sub, D, pp);
 
+    // wave-uniform base (scalar registers) + per-lane 32-bit byte offset (head, dims) -> SADDR-form loads
     const gchar_p kbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)h0 * a.k_hs));
     const gchar_p vbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)h0 * a.v_hs));
     const unsigned klane = (unsigned)(hg * a.k_hs * 2 + sub * 16), vlane = (unsigned)(hg * a.v_hs * 2 + sub * 16);
-    const unsigned kis = (unsigned)(HPI * a.k_hs * 2), vis = (unsigned)(HPI * a.v_hs * 2);  // bytes between a wave's instructions
-    const unsigned krs = (unsigned)(a.k_ts * 2), vrs = (unsigned)(a.v_ts * 2);              // token stride in bytes
+    const unsigned krs = (unsigned)(a.k_ts * 2), vrs = (unsigned)(a.v_ts * 2);  // token stride in bytes
 
-    float m[NI], l[NI], acc[NI][8];
+    float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        m[i] = -INFINITY;
-        l[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-    }
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const float sc = a.scale_log2e;
 
-    struct Buf {
-        u32x4 k[UT][NI], v[UT][NI];
-    };
-    auto issue = [&](Buf& bf, int t0) __attribute__((always_inline)) {
+    // one chunk = UT tokens: all loads first, then the scores, one online-softmax update, then P.V
+    auto chunk = [&](int t0, auto MASKED) __attribute__((always_inline)) {
+        u32x4 kreg[UT], vreg[UT];
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
-            const unsigned tc = (unsigned)min(t0 + u, len - 1);  // never predicate a load: clamp, the score is masked
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                bf.k[u][i] = __builtin_nontemporal_load((gu32x4_p)(kbu + (tc * krs + i * kis + klane)));
-                bf.v[u][i] = __builtin_nontemporal_load((gu32x4_p)(vbu + (tc * vrs + i * vis + vlane)));
-            }
+            // never predicate a load: clamp to the last valid key, its score is forced to -inf below
+            const unsigned tc = (unsigned)(decltype(MASKED)::value ? min(t0 + u, len - 1) : t0 + u);
+            kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + (tc * krs + klane)));
+            vreg[u] = __builtin_nontemporal_load((gu32x4_p)(vbu + (tc * vrs + vlane)));
         }
-    };
-    auto consume = [&](const Buf& bf, int t0, auto MASKED) __attribute__((always_inline)) {
+        float sv[UT];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float sv[UT];
+        for (int u = 0; u < UT; ++u) {
+            float d = 0.f;
 #pragma unroll
-            for (int u = 0; u < UT; ++u) {
-                float d = 0.f;
+            for (int e = 0; e < 4; ++e) d = TR::dot2(qp[e], kreg[u][e], d);
+            d = group_sum<LPK>(d) * sc;
+            sv[u] = (!decltype(MASKED)::value || t0 + u < len) ? d : -INFINITY;  // wave-uniform condition
+        }
+        float cmax = sv[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d = TR::dot2(qp[i][e], bf.k[u][i][e], d);
-                d = group_sum<LPK>(d) * sc;
-                sv[u] = (!decltype(MASKED)::value || t0 + u < len) ? d : -INFINITY;  // wave-uniform condition
-            }
-            float cmax = sv[0];
+        for (int u = 1; u < UT; ++u) cmax = fmaxf(cmax, sv[u]);
+        const float mnew = fmaxf(m, cmax);  // finite: t0 < len
+        const float alpha = fast_exp2(m - mnew);
+        float ps = 0.f;
 #pragma unroll
-            for (int u = 1; u < UT; ++u) cmax = fmaxf(cmax, sv[u]);
-            const float mnew = fmaxf(m[i], cmax);  // finite: t0 < len
-            const float alpha = fast_exp2(m[i] - mnew);
-            float ps = 0.f;
+        for (int u = 0; u < UT; ++u) {
+            sv[u] = fast_exp2(sv[u] - mnew);
+            ps += sv[u];
+        }
+        l = l * alpha + ps;
+        m = mnew;
 #pragma unroll
-            for (int u = 0; u < UT; ++u) {
-                sv[u] = fast_exp2(sv[u] - mnew);
-                ps += sv[u];
-            }
-            l[i] = l[i] * alpha + ps;
-            m[i] = mnew;
+        for (int j = 0; j < 8; ++j) acc[j] *= alpha;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] *= alpha;
+        for (int u = 0; u < UT; ++u) {
+            float vf[8];
+            widen8<T>(vreg[u], vf);
 #pragma unroll
-            for (int u = 0; u < UT; ++u) {
-                float vf[8];
-                widen8<T>(bf.v[u][i], vf);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_fmaf(sv[u], vf[j], acc[i][j]);
-            }
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(sv[u], vf[j], acc[j]);
         }
     };
     using Full = std::integral_constant<bool, false>;
     using Masked = std::integral_constant<bool, true>;
     const int nfull = len / UT;
-    Buf A, Bb;
-    if constexpr (DB == 0) {
-        for (int c = 0; c < nfull; ++c) {
-            issue(A, c * UT);
-            consume(A, c * UT, Full{});
-        }
-    } else if (nfull > 0) {
-        issue(A, 0);
-        int c = 0;
-        for (; c + 2 <= nfull; c += 2) {
-            issue(Bb, (c + 1) * UT);
-            consume(A, c * UT, Full{});
-            if (c + 2 < nfull) issue(A, (c + 2) * UT);
-            consume(Bb, (c + 1) * UT, Full{});
-        }
-        if (c < nfull) consume(A, c * UT, Full{});
+    int c = 0;
+    if constexpr (ROT != 0) {
+        // starting chunk = a 16-bit hash of the sequence index scaled to [0, nfull)
+        c = (int)(((((unsigned)b * 0x9E3779B1u) >> 16) * (unsigned)nfull) >> 16);
     }
-    if (nfull * UT < len) {
-        issue(A, nfull * UT);
-        consume(A, nfull * UT, Masked{});
+    for (int i = 0; i < nfull; ++i) {
+        chunk(c * UT, Full{});
+        c = c + 1 == nfull ? 0 : c + 1;
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) finish_row<T, D, 2, NPRE>(a, ridx[i], sub, m[i], l[i], acc[i], npre, pp[i]);
+    if (nfull * UT < len) chunk(nfull * UT, Masked{});
+    finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
+}
+
+// shapes only (capture-safe): one query row per unit, whole lane groups, 32-bit offsets inside a sequence's cache, and
+// enough waves to fill the chip (below that the keys of a unit are spread over four waves by launch_suffix_r)
+template <int D>
+static bool suffix_rows_eligible(const SuffixArgs& a) {
+    constexpr int HPI = 64 / (D / 8);
+    const int64_t span = (int64_t)a.kv_len * (a.k_ts > a.v_ts ? a.k_ts : a.v_ts) * 2 +
+                         (int64_t)a.Hkv * (a.k_hs > a.v_hs ? a.k_hs : a.v_hs) * 2;
+    return a.rows == 1 && a.nq == 1 && a.g == 1 && a.Hkv % HPI == 0 && span < ((int64_t)1 << 31) && a.n_pre <= 2;
+}
+
+template <typename T, int D>
+static int launch_suffix_rows(const SuffixArgs& a0, hipStream_t s, int ut, int rot) {
+    constexpr int HPI = 64 / (D / 8);
+    SuffixArgs a = a0;
+    const int wps = a.Hkv / HPI;  // waves per sequence
+    a.rows_wps_log2 = wps >= 3 ? 2 : wps == 2 ? 1 : 0;
+    const int wl = a.rows_wps_log2;
+    const dim3 grid((unsigned)((a.B + (4 >> wl) - 1) >> (2 - wl)), (unsigned)((wps + (1 << wl) - 1) >> wl), 1);
+#define HYD_ROWS_LAUNCH(UT_, NPRE_, ROT_) \
+    do { hipLaunchKernelGGL((suffix_attn_rows_kernel<T, D, UT_, NPRE_, ROT_>), grid, dim3(256), 0, s, a); return (int)hipGetLastError(); } while (0)
+#ifdef HYD_ABLATION_BUILD
+    if constexpr (D == 128) {
+        if (a.n_pre < 2) {
+            if (ut == 4) HYD_ROWS_LAUNCH(4, 1, 0);
+            if (ut == 8 && rot) HYD_ROWS_LAUNCH(8, 1, 1);
+        }
+    }
+#endif
+    (void)ut;
+    (void)rot;
+    if (a.n_pre == 2) HYD_ROWS_LAUNCH(8, 2, 0);
+    HYD_ROWS_LAUNCH(8, 1, 0);
+#undef HYD_ROWS_LAUNCH
 }
 
 // NPRE: 16-bit partials fetched under the K/V stream (suffix_common.h); 2 is instantiated for the decode shape only
@@ -456,23 +471,6 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
             hipExtLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1>), grid, dim3(256), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, a);
             return (int)hipGetLastError();
         }
-        // token-row form A/B: HYD_SUFFIX_ROWS = <NI><UT><DB>
-        if constexpr (R == 1 && D == 128) {
-            if (const char* e = getenv("HYD_SUFFIX_ROWS"); e && atoi(e) && a.packed && a.n_pre < 2) {
-                const int v = atoi(e), ni = v / 100;
-                if (a.Hkv % (4 * ni) == 0) {
-                    dim3 g2(a.B, (a.Hkv + 16 * ni - 1) / (16 * ni), 1);
-                    switch (v) {
-#define HYD_ROWS_CASE(NI_, UT_, DB_) \
-    case NI_ * 100 + UT_ * 10 + DB_: hipLaunchKernelGGL((suffix_rows_kernel<T, NI_, UT_, DB_, 1>), g2, dim3(256), 0, s, a); return (int)hipGetLastError();
-                        HYD_ROWS_CASE(1, 2, 1) HYD_ROWS_CASE(1, 4, 1) HYD_ROWS_CASE(1, 4, 0) HYD_ROWS_CASE(1, 8, 0)
-                        HYD_ROWS_CASE(2, 1, 1) HYD_ROWS_CASE(2, 2, 0) HYD_ROWS_CASE(2, 2, 1) HYD_ROWS_CASE(2, 4, 0)
-#undef HYD_ROWS_CASE
-                        default: break;
-                    }
-                }
-            }
-        }
         // occupancy A/B (VERDICT r5 next #1c): key iterations in flight x resident waves per SIMD
         if constexpr (R == 1 && D == 128) {
             if (const char* e = getenv("HYD_SUFFIX_OCC"); e && a.n_pre < 2) {
@@ -510,6 +508,20 @@ template <typename T, int D>
 static int launch_suffix_t(const SuffixArgs& a0, hipStream_t s) {
     SuffixArgs a = a0;
     a.packed = suffix_packed_eligible(a, D) ? 1 : 0;
+    {
+        // token-row kernel: measured faster wherever the one-unit-per-wave kernel would run with one wave per unit
+        // (launch_suffix_r's few_units rule spreads a unit over four waves below 2048 units)
+        // ... and whose caches hold at most 1024 token rows: on longer rows a wave start costs little, and the one-unit-per-wave kernel
+        // streams them as fast or faster (2176-row caches, profiles/r06_suffix_rows_capacity.txt)
+        bool rows = suffix_rows_eligible<D>(a) && !((int64_t)a.units < 2 * 256 * 4 && a.kv_len >= 64) && a.kv_len <= 1024;
+        int ut = 8, rot = 0;
+#ifdef HYD_ABLATION_BUILD
+        if (const char* e = getenv("HYD_SUFFIX_ROWS")) rows = atoi(e) != 0 && suffix_rows_eligible<D>(a);
+        if (const char* e = getenv("HYD_ROWS_UT")) ut = atoi(e);
+        if (const char* e = getenv("HYD_ROWS_ROT")) rot = atoi(e);
+#endif
+        if (rows) return launch_suffix_rows<T, D>(a, s, ut, rot);
+    }
     if (a.rows <= 1) return launch_suffix_r<T, D, 1>(a, s);
     if (a.rows <= 2) return launch_suffix_r<T, D, 2>(a, s);
     if (a.rows <= 4) return launch_suffix_r<T, D, 4>(a, s);

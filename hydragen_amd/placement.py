@@ -102,7 +102,11 @@ def place_kv_arenas(count: int, shape: Sequence[int], dtype: torch.dtype, device
     """`count` K|V arenas of shape [2, *shape] (shape = [batch, rows, kv heads, head dim]) on `device`, each the unique
     cache of one layer, placed where the suffix pass streams fastest among the candidates tried.  Returns (arenas,
     report); report = {"candidates", "spacer_bytes", "probe_us", "kept"} -- or {"candidates": count, "probed": False, "why"}.
-    `probe(arena) -> us` defaults to `probe_suffix_pass_us(arena, qheads)` (qheads = the query heads that will attend to it)."""
+    `probe(arena) -> us` defaults to `probe_suffix_pass_us(arena, qheads)` (qheads = the query heads that will attend to it).
+    Side effects, once per call: up to MAX_FREE_FRACTION (half) of the device's FREE memory is allocated for a moment
+    (candidates + spacers) and `torch.cuda.empty_cache()` runs before returning; ranks that share one device should place
+    their caches one after the other (they would race on `mem_get_info`).  Only a shape the suffix pass refuses (ValueError /
+    NotImplementedError / AssertionError from the operator) falls back to plain allocation, with a warning; runtime faults propagate."""
     dev = torch.device(device)
     full = (2,) + tuple(int(x) for x in shape)
     arena_bytes = math.prod(full) * torch.empty((), dtype=dtype).element_size()
@@ -136,14 +140,20 @@ def place_kv_arenas(count: int, shape: Sequence[int], dtype: torch.dtype, device
     with torch.cuda.device(dev):
         try:
             times = [float(probe(c)) for c in cands]
-        except Exception as ex:  # noqa: BLE001 -- a shape the suffix pass refuses must not cost the caches: first come, first kept
+        except (ValueError, NotImplementedError, AssertionError) as ex:
+            # a SHAPE the suffix pass refuses (bad-argument / unsupported codes of the C ABI, the mirrors' asserts) must not
+            # cost the caches: first come, first kept.  Anything else -- a launch failure, a HIP runtime error, a library that
+            # does not load -- is a real fault and propagates from here, next to its cause, not from a later graph capture.
+            import warnings
+
+            warnings.warn(f"KV placement probe refused this cache shape ({type(ex).__name__}: {str(ex)[:160]}); caches are not placed")
             out = cands[:count]
             del cands, spacers
             torch.cuda.empty_cache()
             if zero:
                 for a in out:
                     a.zero_()
-            return out, {"candidates": count, "probed": False, "why": f"probe failed: {type(ex).__name__}: {str(ex)[:120]}"}
+            return out, {"candidates": count, "probed": False, "why": f"probe refused the shape: {type(ex).__name__}: {str(ex)[:120]}"}
         kept = choose(times, count)
         out = [cands[i] for i in kept]
         del cands, spacers

@@ -69,11 +69,18 @@ def test_fastest_candidates_are_kept_zeroed_and_the_rest_released(monkeypatch):
         seen.clear()
         arenas, rep = P.place_kv_arenas(4, (64, 128, 2, 128), torch.bfloat16, "cuda:0", 8, probe=lambda a: [seen.append(a.data_ptr()), float(len(seen) % 3)][1])
         assert rep["candidates"] == 6 and rep["kept"] == [0, 2, 3, 5] and [a.data_ptr() for a in arenas] == [seen[i] for i in rep["kept"]]
-        # a probe that cannot run leaves plain caches behind, not an exception
+        # a probe that REFUSES THE SHAPE (the C ABI's bad-argument / unsupported codes, the mirrors' asserts) leaves plain caches
+        # behind, with a warning, not an exception ...
+        def refused(a):
+            raise NotImplementedError("hydragen_hip: head_dim 96: only 64, 128 and 256 are implemented")
+        with pytest.warns(UserWarning, match="refused this cache shape"):
+            arenas, rep = P.place_kv_arenas(2, (64, 128, 2, 128), torch.bfloat16, "cuda:0", 8, probe=refused)
+        assert len(arenas) == 2 and not rep["probed"] and "head_dim 96" in rep["why"] and not any(a.any() for a in arenas)
+        # ... but a runtime fault (launch failure, HIP error) is raised here, next to its cause
         def broken(a):
-            raise RuntimeError("no such kernel")
-        arenas, rep = P.place_kv_arenas(2, (64, 128, 2, 128), torch.bfloat16, "cuda:0", 8, probe=broken)
-        assert len(arenas) == 2 and not rep["probed"] and "no such kernel" in rep["why"] and not any(a.any() for a in arenas)
+            raise RuntimeError("hydragen_hip error -4: suffix kernel launch failed: hip error 719")
+        with pytest.raises(RuntimeError, match="launch failed"):
+            P.place_kv_arenas(2, (64, 128, 2, 128), torch.bfloat16, "cuda:0", 8, probe=broken)
     finally:
         P.set_candidates(old)
 

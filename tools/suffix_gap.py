@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--legs", default="sweep,instep,occ")
     ap.add_argument("--occ", default="0,48,38,28,65,84")
-    ap.add_argument("--rows", default="0,121,141,140,180,211,220,221,240")
+    ap.add_argument("--rows", default="0:8:1,1:8:1,1:8:0,1:4:1,1:4:0")
+    ap.add_argument("--S", default="16,32,64,128")
     a = ap.parse_args()
     legs = a.legs.split(",")
     lib = _lib.load()
@@ -155,18 +156,30 @@ def main():
             c5 = times(s, a.iters)
             print(f"| {S} | " + " | ".join(f"{x[0]:6.1f} / {x[1]:6.1f}" for x in (c0, c1, c2, c3, c4, c5)) + " |", flush=True)
 
-    for leg, env, default in (("occ", "HYD_SUFFIX_OCC", a.occ), ("rows", "HYD_SUFFIX_ROWS", a.rows)):
+    def set_variant(v):
+        """occ leg: HYD_SUFFIX_OCC value; rows legs: 'ROWS:UT:ROT' (token-row kernel on/off, tokens in flight, rotated start)."""
+        for k in ("HYD_SUFFIX_OCC", "HYD_SUFFIX_ROWS", "HYD_ROWS_UT", "HYD_ROWS_ROT"):
+            os.environ.pop(k, None)
+        if v is None:
+            return
+        if ":" in v:
+            r_, u_, o_ = v.split(":")
+            os.environ.update(HYD_SUFFIX_ROWS=r_, HYD_ROWS_UT=u_, HYD_ROWS_ROT=o_)
+        else:
+            os.environ.update(HYD_SUFFIX_ROWS="0", HYD_SUFFIX_OCC=v)
+
+    for leg, default in (("occ", a.occ), ("rows", a.rows)):
         if leg not in legs:
             continue
-        print(f"\n## {env} A/B (ablation library only; 0 = shipped) -- unique phase b2b, us min / median; [max |diff| against the shipped kernel's output]")
-        vals = [int(x) for x in default.split(",")]
-        print("| S | " + " | ".join(str(o) for o in vals) + " |")
+        print(f"\n## {leg} A/B (ablation library only; first column = reference) -- unique phase b2b, us min / median; [max |diff| against the first column's output]")
+        vals = default.split(",")
+        print("| S | " + " | ".join(vals) + " |")
         print("|---|" + "---|" * len(vals))
-        for S in (8, 16, 32, 64, 96, 128):
+        for S in [int(x) for x in a.S.split(",")]:
             call, keep = decode_params(S)
             call(HYD_PHASE_SHARED)()
             u = call(HYD_PHASE_UNIQUE)
-            os.environ.pop(env, None)
+            set_variant(vals[0])
             u()
             torch.cuda.synchronize()
             want = out.float().clone()
@@ -174,7 +187,7 @@ def main():
             for rep_ in range(2):  # two passes over the variants: drift shows
                 row = []
                 for o in vals:
-                    os.environ[env] = str(o)
+                    set_variant(o)
                     out.zero_()
                     u()
                     torch.cuda.synchronize()
@@ -182,28 +195,56 @@ def main():
                     mn, md = times(u, a.iters)
                     row.append(f"{mn:6.1f} / {md:6.1f} [{err:.1e}]")
                 cells.append(row)
-            os.environ.pop(env, None)
+            set_variant(None)
             for row in cells:
                 print(f"| {S} | " + " | ".join(row) + " |", flush=True)
 
+    if "capacity" in legs:
+        print("\n## cache capacity (= rows between sequences) x kernel: suffix pass alone, n_partials 1, plain allocations; us median (TB/s)")
+        vals = a.rows.split(",")
+        print("| cache rows | S | " + " | ".join(vals) + " |")
+        print("|---|---|" + "---|" * len(vals))
+        for cap in (128, 144, 256, 512, 1024, 2176):
+            arena = torch.empty((2, B, cap, Hkv, D), dtype=dt, device=DEV)
+            arena.normal_()
+            for S in (64, 128, 512, 2176):
+                if S > cap:
+                    continue
+                fn, keep = suffix_call(arena, S, 1)
+                row = []
+                for o in vals:
+                    set_variant(o)
+                    mn, md = times(fn, max(5, a.iters // (1 + S // 256)))
+                    row.append(f"{md:7.1f} ({alg_bytes(S, 1) / md / 1e6:4.2f})")
+                set_variant(None)
+                print(f"| {cap} | {S} | " + " | ".join(row) + " |", flush=True)
+            del arena
+            torch.cuda.empty_cache()
+
     if "stride" in legs:
-        print("\n## batch stride of the K|V caches: 128 rows + pad bytes between sequences (suffix pass alone, n_partials 1; us min / median)")
-        pads = [0, 256, 1024, 2048, 4096, 8192 + 256, 8192 + 1024, 8192 + 4096, 16384 + 2048, 65536 + 4096]
-        print("| S | " + " | ".join(str(x) for x in pads) + " |")
-        print("|---|" + "---|" * len(pads))
+        print("\n## batch stride of the K|V caches (bytes between sequences; 128 token rows = 1 MiB used per sequence and tensor), suffix pass alone, "
+              "n_partials 1, plain allocation; us median per variant " + a.rows)
+        vals = a.rows.split(",")
         row_el = Hkv * D
-        rowsS = {}
-        for pad in pads:
-            bs = 128 * row_el + pad // 2
-            flat = torch.randn(2 * B * bs, device=DEV, dtype=dt)
+        pads = [k * 512 for k in range(0, 33)] + [24 << 10, 32 << 10, 48 << 10, 64 << 10, 96 << 10, 128 << 10, 192 << 10, 256 << 10, 384 << 10, 512 << 10]
+        strides = [128 * row_el * 2 + p_ for p_ in pads] + [r_ * row_el * 2 for r_ in (160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024, 1536, 2048, 2176)]
+        print("| stride bytes | = rows + pad | " + " | ".join(f"S=64 {v}" for v in vals) + " | " + " | ".join(f"S=128 {v}" for v in vals) + " |")
+        print("|---|---|" + "---|" * (2 * len(vals)))
+        for sb in strides:
+            bs = sb // 2  # elements
+            flat = torch.empty(2 * B * bs, device=DEV, dtype=dt)
+            flat.normal_()
             kk = flat[: B * bs].as_strided((B, 128, Hkv, D), (bs, row_el, D, 1))
             vv = flat[B * bs:].as_strided((B, 128, Hkv, D), (bs, row_el, D, 1))
-            for S in (32, 64, 128):
+            cells = []
+            for S in (64, 128):
                 fn, keep = suffix_call((kk, vv), S, 1)
-                rowsS.setdefault(S, []).append("%6.1f / %6.1f" % times(fn, a.iters))
+                for o in vals:
+                    set_variant(o)
+                    cells.append("%6.1f" % times(fn, a.iters)[1])
+                set_variant(None)
+            print(f"| {sb} | {sb // (row_el * 2)} rows + {sb % (row_el * 2)} | " + " | ".join(cells) + " |", flush=True)
             del flat, kk, vv
-        for S, r in rowsS.items():
-            print(f"| {S} | " + " | ".join(r) + " |", flush=True)
 
 
 if __name__ == "__main__":
