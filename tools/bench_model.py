@@ -20,9 +20,16 @@ ap.add_argument("--new", type=int, default=128)
 ap.add_argument("--modes", default="hydragen,noattention")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--tunableop", default="", help="PyTorch TunableOp results file (tools/tune_gemms.py) to select the GEMM solutions from; tuning itself stays off")
 ap.add_argument("--tp-slice", type=int, default=1, help="build rank 0's shard of an N-way tensor-parallel model (no collectives: per-GPU compute only)")
 a = ap.parse_args()
 
+if a.tunableop:
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.tuning_enable(False)
+    ok = tun.read_file(a.tunableop)
+    print(json.dumps({"tunableop_file": a.tunableop, "read_ok": bool(ok), "enabled": tun.is_enabled(), "entries": len(tun.get_results())}))
 cfg = LlamaConfig.llama2_7b() if a.model == "llama2-7b" else LlamaConfig.llama3_70b()
 if a.layers:
     cfg.num_hidden_layers = a.layers
