@@ -93,6 +93,11 @@ def parse():
     ap.add_argument("--no-model", action="store_true", help="skip the Llama-2-7B decode tokens/s leg")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--no-paper-sweep", action="store_true", help="skip the reference microbenchmark's own sweep corners (8 q / 1 kv heads)")
+    ap.add_argument("--step-form", choices=("eager", "graph"), default="eager",
+                    help="how a timed step without events issues the operator: one eager C call (hyd_decode_attn_fused; the default since round 6: "
+                         "2-4 us per step less than a graph replay on this stack, tests/probes/eager_vs_graph_probe.py) or one replay of its "
+                         "captured HIP graph (rounds 1-5; the reference's own protocol, hydragen/benchmark_utils.py:140-170, stays graph-based in "
+                         "`reference_protocol`); the other form is timed once in `trials.other_form_us_per_step`")
     ap.add_argument("--two-stream", action="store_true",
                     help="steps replay the two-stream form of the operator instead of the one-call form (A/B; DESIGN 4.8)")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -216,8 +221,12 @@ class Ops:
             self.graphs[key] = _capture(fn)
         return self.graphs[key]
 
-    def step(self, s):
-        self.graph(s).replay()
+    def step(self, s, form="graph"):
+        """One pass of the operator: a replay of its captured graph, or (form "eager", one-call form only) one C call on the current stream."""
+        if form == "eager" and not self.two_stream:
+            self.fused(s, torch.cuda.current_stream().cuda_stream)
+        else:
+            self.graph(s).replay()
 
 
 def _respawn(n: int) -> int:
@@ -290,9 +299,9 @@ def main():
         else:  # gloo self-test: reduce a host copy
             dist.all_reduce(ar_host)
 
-    def step(s, ev=None):
-        if ev is None:  # the operator as the decode loop runs it: one replay of its captured graph
-            ops.step(s)
+    def step(s, ev=None, form=None):
+        if ev is None:  # the operator in one piece: one eager C call (two kernel launches) or one replay of its captured graph
+            ops.step(s, form or args.step_form)
             if world > 1:
                 collective()
             return
@@ -315,11 +324,13 @@ def main():
 
     # Per-kernel durations need the two kernels one after the other with an event between them, so the steps that carry
     # events run the operator eagerly IN ORDER (three records cost ~10 us of such a step); all other steps replay the
-    # captured two-stream graph.  Event steps: i % 4 == 1 in the first half of the schedule and their mirror images
-    # K-1-i -- the schedule is a uniform cover, so this subset has exactly the mean suffix length of all K steps.
-    # Fewer than 8 steps: every step.
+    # captured graph.  Event steps: i % 5 == 1 in the first half of the schedule and their mirror images K-1-i (one step
+    # in five; K = 20: suffix 10, 42, 87, 119) -- the schedule is a uniform cover, so this subset has the mean suffix length of
+    # all K steps.  (Until round 5: i % 4 == 1, six of twenty steps; the event records are instrumentation that the timed region
+    # pays for, ~10 us per such step, and timing events inside a captured graph are refused on this stack:
+    # tests/probes/graph_event_probe.py.)  Fewer than 8 steps: every step.
     K_ = args.steps
-    ev_idx = sorted({i for i in range(K_ // 2) if i % 4 == 1} | {K_ - 1 - i for i in range(K_ // 2) if i % 4 == 1}) \
+    ev_idx = sorted({i for i in range(K_ // 2) if i % 5 == 1} | {K_ - 1 - i for i in range(K_ // 2) if i % 5 == 1}) \
         if K_ >= 8 else list(range(K_))
     nev = 4 if world > 1 else 3
     ev_of = {i: [torch.cuda.Event(enable_timing=True) for _ in range(nev)] for i in ev_idx}
@@ -362,6 +373,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ = float(t.item())
         trial_us.append(dt_ / args.steps * 1e6)
+
+    other_form = "graph" if (args.step_form == "eager" and not args.two_stream) else "eager"
+    other_us = None
+    if args.trials and not args.two_stream:  # the same schedule once more in the OTHER step form (graph replays <-> eager calls)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(sched[i], form=other_form)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        other_us = (time.perf_counter() - t1) / args.steps * 1e6
 
     if region_dog is not None:
         region_dog.cancel()
@@ -443,18 +468,19 @@ def main():
         "kv_placement": ({"candidates": kv_place["candidates"], "probe_us": kv_place["probe_us"], "kept": kv_place["kept"][0],
                           "spacer_gib": round(kv_place["spacer_bytes"] / 2**30, 1)} if kv_place.get("probed") else
                          {"candidates": 1, "why": kv_place.get("why")}),
-        "step_forms": {"graph_replay_steps": args.steps - n_ev,
+        "step_forms": {"form": "graph" if args.two_stream else args.step_form, "steps_in_that_form": args.steps - n_ev,
                        "graph_form": "one-call form (hyd_decode_attn_fused: prefix pass, then suffix pass with the merge in its epilogue)"
                        if not args.two_stream else
                        "two-stream form: shared phase (persistent prefix workgroups on half of the CUs) on a side stream || "
                        "unique phase, join, log-sum-exp merge (hydragen_amd.attention.set_two_stream)",
                        "eager_in_order_steps_with_events": n_ev},
-        "events": {"steps_with_events": n_ev, "rule": "i % 4 == 1 in the first half of the schedule + mirror images K-1-i" if n_ev < args.steps else "every step",
+        "events": {"steps_with_events": n_ev, "rule": "i % 5 == 1 in the first half of the schedule + mirror images K-1-i" if n_ev < args.steps else "every step",
                    "steps": ev_idx, "suffix_lens": sched_ev, "suffix_len_mean": sum(sched_ev) / n_ev,
                    "why": "a kernel's own duration needs the two kernels in order with an event between them; these steps run the "
                           "operator eagerly in that form, the per-kernel rooflines are theirs"},
-        "trials": {"headline": "trial 0 = the timed region above (HIP events on half of its steps)", "trial0_us_per_step": elapsed / args.steps * 1e6,
-                   "repeat_us_per_step": trial_us, "repeat_note": "same schedule, every step a graph replay, no events, each bracketed like the headline",
+        "trials": {"headline": "trial 0 = the timed region above (HIP events on one step in five)", "trial0_us_per_step": elapsed / args.steps * 1e6,
+                   "repeat_us_per_step": trial_us, "repeat_note": "same schedule, every step in the headline's step form, no events, each bracketed like the headline",
+                   "other_form": other_form, "other_form_us_per_step": other_us,
                    **({"repeat_mean_us": sum(trial_us) / len(trial_us), "repeat_min_us": min(trial_us), "repeat_max_us": max(trial_us)} if trial_us else {})},
         "suffix_frac_by_suffix_len": buckets,
         "roofline": suffix_roof if dominant_is_suffix else prefix_roof,

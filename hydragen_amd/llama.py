@@ -221,11 +221,12 @@ class PerLayerKVCache(nn.Module):
                  n_kv_heads, head_dim, device, dtype, arena: Optional[Tensor] = None):
         super().__init__()
         shape = (max_unique_batch_size, max_unique_seq_length, n_kv_heads, head_dim)
-        # One allocation, K | V (the reference's two attribute names, llama.py:186-198, stay as views).  The arena itself is neutral
-        # for speed (no K-V gap or batch stride matters); WHERE it sits in HBM is not (profiles/r05_gqa_placement.md): `setup_caches`
-        # hands in arenas chosen by hydragen_amd/placement.py; without one, a plain allocation as the reference's.
+        # One allocation per layer (the reference's two attribute names, llama.py:186-198, stay as views of it): a sequence's K rows,
+        # then its V rows (placement.kv_arena: the suffix pass streams that 1.5-3 % faster than all K, then all V).  WHERE the arena
+        # sits in HBM matters too (profiles/r05_gqa_placement.md): `setup_caches` hands in arenas chosen by hydragen_amd/placement.py;
+        # without one, a plain allocation of the same layout.
         if arena is None:
-            arena = torch.zeros((2,) + shape, dtype=dtype, device=device)
+            arena = placement.kv_arena(shape, dtype, device, zero=True)
         assert tuple(arena.shape) == (2,) + shape and arena.dtype == dtype, f"{tuple(arena.shape)} {arena.dtype}"
         self.register_buffer("per_completion_k_cache", arena[0])
         self.register_buffer("per_completion_v_cache", arena[1])

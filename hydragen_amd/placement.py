@@ -33,6 +33,18 @@ MIN_ARENA_BYTES = 512 << 20   # at or near the 256 MB memory-side cache's size p
 MAX_FREE_FRACTION = 0.5       # of the device's free memory, the most the candidates + spacers may take transiently
 
 
+def kv_arena(shape: Sequence[int], dtype: torch.dtype, device, zero: bool = True) -> Tensor:
+    """One layer's unique K|V cache, logical shape [2 (K | V), batch, rows, kv heads, head dim] -- `arena[0]` / `arena[1]` are the
+    reference's two caches (`/root/reference/hydragen/llama.py:186-198`) -- laid out in memory as [batch, 2, rows, kv heads, head dim]:
+    a sequence's K rows, then its V rows.  Same bytes, but consecutive sequences sit 2 x rows token rows apart instead of `rows`, and
+    the suffix pass streams a 128-row cache 1.5-3 % faster that way (both kernels, three fresh allocations of each layout,
+    alternating: 167-169 -> 164-167 us at S = 64, 327-330 -> 320-325 at S = 128, profiles/r06_kv_arena_layout_ab.txt; the rate grows
+    with the distance between sequences up to 512 rows, profiles/r06_suffix_rows_capacity.txt).  The operators take strided K / V."""
+    b, rows, hkv, d = (int(x) for x in shape)
+    make = torch.zeros if zero else torch.empty
+    return make((b, 2, rows, hkv, d), dtype=dtype, device=device).permute(1, 0, 2, 3, 4)
+
+
 def set_candidates(n: int) -> int:
     """Candidates per arena (1 = no probing).  Returns the previous setting."""
     global _candidates
@@ -99,8 +111,8 @@ def plan(count: int, arena_bytes: int, free_bytes: int, candidates: int) -> tupl
 
 def place_kv_arenas(count: int, shape: Sequence[int], dtype: torch.dtype, device, qheads: int, *, zero: bool = True,
                     probe: Callable[[Tensor], float] | None = None) -> tuple[list[Tensor], dict]:
-    """`count` K|V arenas of shape [2, *shape] (shape = [batch, rows, kv heads, head dim]) on `device`, each the unique
-    cache of one layer, placed where the suffix pass streams fastest among the candidates tried.  Returns (arenas,
+    """`count` K|V arenas of logical shape [2, *shape] (shape = [batch, rows, kv heads, head dim]; memory layout: `kv_arena`) on
+    `device`, each the unique cache of one layer, placed where the suffix pass streams fastest among the candidates tried.  Returns (arenas,
     report); report = {"candidates", "spacer_bytes", "probe_us", "kept"} -- or {"candidates": count, "probed": False, "why"}.
     `probe(arena) -> us` defaults to `probe_suffix_pass_us(arena, qheads)` (qheads = the query heads that will attend to it).
     Side effects, once per call: up to MAX_FREE_FRACTION (half) of the device's FREE memory is allocated for a moment
@@ -110,10 +122,9 @@ def place_kv_arenas(count: int, shape: Sequence[int], dtype: torch.dtype, device
     dev = torch.device(device)
     full = (2,) + tuple(int(x) for x in shape)
     arena_bytes = math.prod(full) * torch.empty((), dtype=dtype).element_size()
-    make = torch.zeros if zero else torch.empty
 
     def plain(why: str):
-        return [make(full, dtype=dtype, device=dev) for _ in range(count)], {"candidates": count, "probed": False, "why": why}
+        return [kv_arena(shape, dtype, dev, zero) for _ in range(count)], {"candidates": count, "probed": False, "why": why}
 
     if dev.type != "cuda":
         return plain("not a GPU allocation")
@@ -129,7 +140,7 @@ def place_kv_arenas(count: int, shape: Sequence[int], dtype: torch.dtype, device
     cands, spacers = [], []
     try:
         for i in range(n):
-            cands.append(torch.empty(full, dtype=dtype, device=dev))
+            cands.append(kv_arena(shape, dtype, dev, zero=False))
             if spacer and i + 1 < n:
                 spacers.append(torch.empty((spacer,), dtype=torch.uint8, device=dev))
     except torch.cuda.OutOfMemoryError:

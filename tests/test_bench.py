@@ -192,7 +192,7 @@ def test_launch_schedule_is_what_a_profiler_sees():
     assert len(ls) == 3 * 25 + 5 + 20 and abs(sum(ls) / len(ls) - 64.6) < 0.05
     assert len(bench.launch_schedule(20, 5, 3, 128)) == len(ls) + 60
     sched = bench.suffix_schedule(20, 128)
-    ev = sorted({i for i in range(10) if i % 4 == 1} | {19 - i for i in range(10) if i % 4 == 1})
+    ev = sorted({i for i in range(10) if i % 5 == 1} | {19 - i for i in range(10) if i % 5 == 1})
     assert abs(sum(sched[i] for i in ev) / len(ev) - sum(sched) / 20) < 0.2  # event steps: the schedule's mean suffix
 
 

@@ -67,11 +67,16 @@ def times(fn, iters, pre=None, sync_each=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--shape", default="", help="B,Hq,Hkv instead of C2's 1024,32,32 (legs that take the suffix pass alone: interleave, capacity, stride)")
+    ap.add_argument("--caps", default="128,144", help="interleave leg: cache rows")
     ap.add_argument("--legs", default="sweep,instep,occ")
     ap.add_argument("--occ", default="0,48,38,28,65,84")
     ap.add_argument("--rows", default="0:8:1,1:8:1,1:8:0,1:4:1,1:4:0")
     ap.add_argument("--S", default="16,32,64,128")
     a = ap.parse_args()
+    global B, Hq, Hkv
+    if a.shape:
+        B, Hq, Hkv = (int(x) for x in a.shape.split(","))
     legs = a.legs.split(",")
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
@@ -80,10 +85,11 @@ def main():
     out = torch.empty_like(q)
     pout = torch.randn(B, 1, Hq, D, device=DEV, dtype=dt, generator=g)
     plse = torch.randn(B, 1, Hq, device=DEV, dtype=torch.float32, generator=g)
-    arenas, rep = placement.place_kv_arenas(1, [B, 128, Hkv, D], dt, DEV, Hq, zero=False)
-    a128 = arenas[0]
-    a128.normal_()
-    print("placement:", rep, flush=True)
+    if set(legs) & {"sweep", "instep", "occ", "rows"}:
+        arenas, rep = placement.place_kv_arenas(1, [B, 128, Hkv, D], dt, DEV, Hq, zero=False)
+        a128 = arenas[0]
+        a128.normal_()
+        print("placement:", rep, flush=True)
 
     def suffix_call(arena, S, np_):
         lens = torch.full((B,), S, dtype=torch.int32, device=DEV)
@@ -219,6 +225,36 @@ def main():
                 set_variant(None)
                 print(f"| {cap} | {S} | " + " | ".join(row) + " |", flush=True)
             del arena
+            torch.cuda.empty_cache()
+
+    if "interleave" in legs:
+        print("\n## K|V arena layout: [2, B, rows, Hkv, D] (K of all sequences, then V: sequences `rows` token rows apart) against [B, 2, rows, Hkv, D] "
+              "(a sequence's K then its V: sequences 2 x rows apart at no extra memory); suffix pass alone, n_partials 1, plain allocations, "
+              "three fresh allocations of each, alternating; us median")
+        vals = a.rows.split(",")
+        print("| cache rows | layout | alloc | " + " | ".join(f"S=rows/{d_} {v}" for d_ in (4, 2, 1) for v in vals) + " |")
+        print("|---|---|---|" + "---|" * (3 * len(vals)))
+        for cap in [int(x) for x in a.caps.split(",")]:
+            held = []
+            for rep_ in range(3):
+                for layout in ("2,B", "B,2"):
+                    if layout == "2,B":
+                        arena = torch.empty((2, B, cap, Hkv, D), dtype=dt, device=DEV)
+                        kk, vv = arena[0], arena[1]
+                    else:
+                        arena = torch.empty((B, 2, cap, Hkv, D), dtype=dt, device=DEV)
+                        kk, vv = arena[:, 0], arena[:, 1]
+                    arena.normal_()
+                    held.append(arena)  # keep it: the next allocation lands somewhere else
+                    cells = []
+                    for S in (cap // 4, cap // 2, cap):
+                        fn, keep = suffix_call((kk, vv), S, 1)
+                        for o in vals:
+                            set_variant(o)
+                            cells.append("%6.1f" % times(fn, a.iters)[1])
+                        set_variant(None)
+                    print(f"| {cap} | [{layout}] | {rep_} | " + " | ".join(cells) + " |", flush=True)
+            del held
             torch.cuda.empty_cache()
 
     if "stride" in legs:
