@@ -119,20 +119,163 @@ __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, i
 // instruction covers -- C2 and its tensor-parallel shards): a wave walks the token rows of ONE sequence for HPI neighbouring
 // heads.  A lane group of D / 8 lanes owns one head outright (all of its keys arrive in the same lanes): one wave instruction
 // fetches 1 KB contiguous, the waves of a workgroup sit side by side on the token row (4 KB contiguous per token and tensor),
-// UT tokens x 2 tensors (16 KB at UT = 8) in flight per wave.  No merge across lane groups or waves at the end, and a quarter
+// UT tokens x 2 tensors (16 KB at UT = 8) per wave.  No merge across lane groups or waves at the end, and a quarter
 // of the waves (wave starts, page touches, epilogues, q / partial / output rows of 256 B) of the one-unit-per-wave kernel
-// below, which splits the keys of ONE head over a wave's four lane groups.
-// Measured at C2 (profiles/r06_suffix_rows_*.txt; same box, same arena, alternating): 165 vs 173 us at S = 64, 318 vs 337 at
-// S = 128, 87.6 vs 90.8 at S = 32, equal at S <= 16; UT = 8 beats 4 / 12 / 16, two heads per lane group, a second buffer,
-// eight-wave workgroups and head-major launch order all measured equal or worse.
-// ROT (development builds only): the full chunks of a sequence are walked from a per-sequence starting chunk (softmax does not
-// care about the order), so that workgroups that start together do not touch the same token offsets of caches that sit a
-// pathological distance apart.  Measured (profiles/r06_suffix_stride_sweep.txt): it rescues the bad strides (129 rows between
-// sequences: 193 vs 212 us at S = 64, the one-unit-per-wave kernel 243) and costs 2-10 % on the good ones (128 / 256 / 512 / 2048
-// rows, S = 128: 345 vs 332, 350 vs 318), which are the ones cache allocations have (capacities are multiples of 16 rows): not shipped.
+// further down, which splits the keys of ONE head over a wave's four lane groups.
+// Measured at C2 (profiles/r06_suffix_rows_*.txt; same box, same arena, alternating), first form (all of a chunk's loads,
+// then all of its arithmetic): 165 vs 173 us at S = 64, 318 vs 337 at S = 128, 87.6 vs 90.8 at S = 32, equal at S <= 16; UT = 8
+// beats 4 / 12 / 16, two heads per lane group, a second buffer, eight-wave workgroups and head-major launch order all measured
+// equal or worse.
 // Shapes with fewer than 4 waves per sequence put 4 / wps sequences into one workgroup (a.rows_wps_log2).
-template <typename T, int D, int UT, int NPRE, int ROT>
+//
+// The product form rotates the two register sets instead of doubling them: K of chunk c + 1 is requested as soon as the scores
+// of chunk c are out of the K registers, V of chunk c + 1 as soon as P.V of chunk c is out of the V registers -- the registers
+// of the single-buffer form (116 VGPRs, 4 waves per SIMD), but a wave always has 8 KB in flight while it computes.  The last,
+// partial chunk rides the same pipeline with clamped token indices (never a predicated load).  The sequence's length travels
+// as a VECTOR load in front of q and the prefetched partial (a scalar load's lgkmcnt(0) would serialise it with every later
+// kernel-argument fetch), the argument block's four scalar-cache lines are touched at once, and the lane offsets are computed
+// so that the first K request does not wait for the partial's LSE (see `khg`).  Measured against the first form, one process,
+// alternating (profiles/r06_suffix_rows_pipelined_ab.txt): S = 8 28.5 -> 27.9 us, S = 16 50.3 -> 48.5, S = 32 92.0 -> 90.2,
+// S = 64 175.8 -> 172.8 (-1.7 %), S = 128 340 -> 337; equal at S <= 4.  Requesting (half of) chunk 0's K BEFORE the length is
+// known (HS > 0, development builds) adds nothing on top (the launch is throughput-bound, not start-latency-bound) and costs
+// 1.5 us at S = 1..2 (rows past the length are fetched for nothing): not shipped.
+template <typename T, int D, int UT, int NPRE, int HS = 0>
 __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixArgs a) {
+    using TR = Traits<T>;
+    warm_kernargs_256();  // the fields in front of partials[1] span four scalar-cache lines: one miss time instead of five in a row
+    constexpr int LPK = D / 8, HPI = 64 / LPK;  // lanes per head row, heads per wave instruction
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane % LPK, hg = lane / LPK;
+    // waves per sequence inside a workgroup: 4 (then blockIdx.y walks further head slices), 2 or 1
+    const int wl = a.rows_wps_log2;
+    const int b = (int)(blockIdx.x << (2 - wl)) + (wave >> wl);
+    const int h0 = (int)((blockIdx.y << wl) + (wave & ((1 << wl) - 1))) * HPI;  // first head of this wave
+    if (b >= a.B || h0 >= a.Hkv) return;
+
+    // the length as a vector load: every lane the same address; an opaque zero keeps hipcc from making it a scalar load
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    int lenv = a.kv_len;
+    if (a.sl32) lenv = a.sl32[b + zero];
+    else if (a.sl64) lenv = (int)a.sl64[b + zero];
+
+    const int64_t ridx = (int64_t)b * a.Hq + h0 + hg;  // nq == 1, g == 1: [B, 1, Hq]
+    const u32x4 qp = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.q) + ridx * D + sub * 8);
+    PrePartials<NPRE> pp;
+    const int npre = min(n_prefetched(a), NPRE);
+    prefetch_partials(a, npre, ridx, sub, D, pp);
+
+    // wave-uniform base (scalar registers) + per-lane 32-bit byte offset (head, dims) -> SADDR-form loads
+    const gchar_p kbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.k) + (int64_t)b * a.k_bs + (int64_t)h0 * a.k_hs));
+    const gchar_p vbu = uniform_ptr(reinterpret_cast<const char*>(static_cast<const uint16_t*>(a.v) + (int64_t)b * a.v_bs + (int64_t)h0 * a.v_hs));
+    // (product and sum kept apart: fused, hipcc emits a 64-bit multiply-add whose unused high addend lands in the register the
+    // partial's LSE is being loaded into, and the first K request waits for that load)
+    unsigned khg = (unsigned)hg * (unsigned)(a.k_hs * 2), vhg = (unsigned)hg * (unsigned)(a.v_hs * 2);
+    asm volatile("" : "+v"(khg), "+v"(vhg));
+    const unsigned klane = khg + sub * 16, vlane = vhg + sub * 16;
+    const unsigned krs = (unsigned)(a.k_ts * 2), vrs = (unsigned)(a.v_ts * 2);  // token stride in bytes
+
+    u32x4 kreg[UT], vreg[UT];
+    if constexpr (HS > 0) {  // development builds: K of the first HS token rows before the length is known (the launcher checks the cache holds them)
+#pragma unroll
+        for (int u = 0; u < HS; ++u) kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + ((unsigned)u * krs + klane)));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const float sc = a.scale_log2e;
+
+    const int len = max(0, min(__builtin_amdgcn_readfirstlane(lenv), a.kv_len));
+    const int nch = (len + UT - 1) / UT;  // chunks with at least one key
+    const int last = max(len - 1, 0);
+
+    // requests of a chunk: token indices clamped to the last valid key (never a predicated load); its score is masked below
+    auto issue_k = [&](int c, int u0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            if (u < u0) continue;
+            const unsigned tc = (unsigned)min(c * UT + u, last);
+            kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + (tc * krs + klane)));
+        }
+    };
+    auto issue_v = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const unsigned tc = (unsigned)min(c * UT + u, last);
+            vreg[u] = __builtin_nontemporal_load((gu32x4_p)(vbu + (tc * vrs + vlane)));
+        }
+    };
+    // one chunk out of the registers.  LAST = false: a full chunk that is not the sequence's last one (all UT keys valid; the
+    // next chunk's K / V are requested as soon as this one's are out of their registers).  LAST = true: the sequence's final
+    // chunk, masked by the length, nothing requested behind it.
+    auto chunk = [&](int c, auto LAST) __attribute__((always_inline)) {
+        constexpr bool is_last = decltype(LAST)::value;
+        float sv[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d = TR::dot2(qp[e], kreg[u][e], d);
+            d = group_sum<LPK>(d) * sc;
+            sv[u] = (!is_last || c * UT + u < len) ? d : -INFINITY;  // wave-uniform condition
+        }
+        if constexpr (!is_last) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_k(c + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float cmax = sv[0];
+#pragma unroll
+        for (int u = 1; u < UT; ++u) cmax = fmaxf(cmax, sv[u]);
+        const float mnew = fmaxf(m, cmax);  // finite: every chunk that is processed starts with a valid key
+        const float alpha = fast_exp2(m - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            sv[u] = fast_exp2(sv[u] - mnew);
+            ps += sv[u];
+        }
+        l = l * alpha + ps;
+        m = mnew;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            float vf[8];
+            widen8<T>(vreg[u], vf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(sv[u], vf[j], acc[j]);
+        }
+        if constexpr (!is_last) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_v(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (nch > 0 || HS > 0) {  // (an empty sequence requests nothing: its cache may have no rows at all)
+        issue_k(0, HS);  // chunk 0 in the steady state's order: K, then V
+        issue_v(0);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 1 < nch; ++c) chunk(c, std::integral_constant<bool, false>{});
+        if (nch > 0) chunk(c, std::integral_constant<bool, true>{});
+    }
+    finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
+}
+
+#ifdef HYD_ABLATION_BUILD
+// The first form of the token-row kernel (all of a chunk's loads, then all of its arithmetic), kept in development builds for the
+// A/B tables of profiles/r06_suffix_rows_*.txt (HYD_ROWS_PIPE=0).  ROT: the full chunks of a sequence are walked from a
+// per-sequence starting chunk (softmax does not care about the order), so that workgroups that start together do not touch the
+// same token offsets of caches that sit a pathological distance apart.  Measured (profiles/r06_suffix_stride_sweep.txt): it
+// rescues the bad strides (129 rows between sequences: 193 vs 212 us at S = 64, the one-unit-per-wave kernel 243) and costs
+// 2-10 % on the good ones (128 / 256 / 512 / 2048 rows, S = 128: 345 vs 332, 350 vs 318), which are the ones cache allocations
+// have (capacities are multiples of 16 rows): not shipped.
+template <typename T, int D, int UT, int NPRE, int ROT>
+__global__ __launch_bounds__(256, 4) void suffix_attn_rows1_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int LPK = D / 8, HPI = 64 / LPK;  // lanes per head row, heads per wave instruction
     const int lane = threadIdx.x & 63;
@@ -223,6 +366,7 @@ __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixAr
     if (nfull * UT < len) chunk(nfull * UT, Masked{});
     finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
 }
+#endif  // HYD_ABLATION_BUILD
 
 // shapes only (capture-safe): one query row per unit, whole lane groups, 32-bit offsets inside a sequence's cache, and
 // enough waves to fill the chip (below that the keys of a unit are spread over four waves by launch_suffix_r)
@@ -235,27 +379,31 @@ static bool suffix_rows_eligible(const SuffixArgs& a) {
 }
 
 template <typename T, int D>
-static int launch_suffix_rows(const SuffixArgs& a0, hipStream_t s, int ut, int rot) {
+static int launch_suffix_rows(const SuffixArgs& a0, hipStream_t s, int ut, int rot, int pipe) {
     constexpr int HPI = 64 / (D / 8);
     SuffixArgs a = a0;
     const int wps = a.Hkv / HPI;  // waves per sequence
     a.rows_wps_log2 = wps >= 3 ? 2 : wps == 2 ? 1 : 0;
     const int wl = a.rows_wps_log2;
     const dim3 grid((unsigned)((a.B + (4 >> wl) - 1) >> (2 - wl)), (unsigned)((wps + (1 << wl) - 1) >> wl), 1);
-#define HYD_ROWS_LAUNCH(UT_, NPRE_, ROT_) \
-    do { hipLaunchKernelGGL((suffix_attn_rows_kernel<T, D, UT_, NPRE_, ROT_>), grid, dim3(256), 0, s, a); return (int)hipGetLastError(); } while (0)
+#define HYD_ROWS_LAUNCH(KERNEL) \
+    do { hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, s, a); return (int)hipGetLastError(); } while (0)
 #ifdef HYD_ABLATION_BUILD
     if constexpr (D == 128) {
         if (a.n_pre < 2) {
-            if (ut == 4) HYD_ROWS_LAUNCH(4, 1, 0);
-            if (ut == 8 && rot) HYD_ROWS_LAUNCH(8, 1, 1);
+            if (pipe == 0 && ut == 4) HYD_ROWS_LAUNCH((suffix_attn_rows1_kernel<T, D, 4, 1, 0>));
+            if (pipe == 0 && rot) HYD_ROWS_LAUNCH((suffix_attn_rows1_kernel<T, D, 8, 1, 1>));
+            if (pipe == 0) HYD_ROWS_LAUNCH((suffix_attn_rows1_kernel<T, D, 8, 1, 0>));
+            if (pipe == 1 && a.kv_len >= 4) HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 1, 4>));
+            if (pipe == 2 && a.kv_len >= 2) HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 1, 2>));
         }
     }
 #endif
     (void)ut;
     (void)rot;
-    if (a.n_pre == 2) HYD_ROWS_LAUNCH(8, 2, 0);
-    HYD_ROWS_LAUNCH(8, 1, 0);
+    (void)pipe;
+    if (a.n_pre == 2) HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 2>));
+    HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 1>));
 #undef HYD_ROWS_LAUNCH
 }
 
@@ -514,13 +662,14 @@ static int launch_suffix_t(const SuffixArgs& a0, hipStream_t s) {
         // ... and whose caches hold at most 1024 token rows: on longer rows a wave start costs little, and the one-unit-per-wave kernel
         // streams them as fast or faster (2176-row caches, profiles/r06_suffix_rows_capacity.txt)
         bool rows = suffix_rows_eligible<D>(a) && !((int64_t)a.units < 2 * 256 * 4 && a.kv_len >= 64) && a.kv_len <= 1024;
-        int ut = 8, rot = 0;
+        int ut = 8, rot = 0, pipe = 3;  // pipe (development builds): 0 = the first form, 1 / 2 = blind K requests, 3 = the product form
 #ifdef HYD_ABLATION_BUILD
+        if (const char* e = getenv("HYD_ROWS_PIPE")) pipe = atoi(e);
         if (const char* e = getenv("HYD_SUFFIX_ROWS")) rows = atoi(e) != 0 && suffix_rows_eligible<D>(a);
         if (const char* e = getenv("HYD_ROWS_UT")) ut = atoi(e);
         if (const char* e = getenv("HYD_ROWS_ROT")) rot = atoi(e);
 #endif
-        if (rows) return launch_suffix_rows<T, D>(a, s, ut, rot);
+        if (rows) return launch_suffix_rows<T, D>(a, s, ut, rot, pipe);
     }
     if (a.rows <= 1) return launch_suffix_r<T, D, 1>(a, s);
     if (a.rows <= 2) return launch_suffix_r<T, D, 2>(a, s);

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--shape", default="", help="B,Hq,Hkv instead of C2's 1024,32,32 (legs that take the suffix pass alone: interleave, capacity, stride)")
     ap.add_argument("--caps", default="128,144", help="interleave leg: cache rows")
+    ap.add_argument("--layouts", default="2,B;B,2", help="interleave leg: K|V arena layouts, of 2,B  B,2  B,r,2  B,r,H,2 (semicolon-separated)")
     ap.add_argument("--legs", default="sweep,instep,occ")
     ap.add_argument("--occ", default="0,48,38,28,65,84")
     ap.add_argument("--rows", default="0:8:1,1:8:1,1:8:0,1:4:1,1:4:0")
@@ -163,14 +164,14 @@ def main():
             print(f"| {S} | " + " | ".join(f"{x[0]:6.1f} / {x[1]:6.1f}" for x in (c0, c1, c2, c3, c4, c5)) + " |", flush=True)
 
     def set_variant(v):
-        """occ leg: HYD_SUFFIX_OCC value; rows legs: 'ROWS:UT:ROT' (token-row kernel on/off, tokens in flight, rotated start)."""
-        for k in ("HYD_SUFFIX_OCC", "HYD_SUFFIX_ROWS", "HYD_ROWS_UT", "HYD_ROWS_ROT"):
+        """occ leg: HYD_SUFFIX_OCC value; rows legs: 'ROWS:UT:ROT[:PIPE]' (token-row kernel on/off, tokens in flight, rotated start, pipelined form)."""
+        for k in ("HYD_SUFFIX_OCC", "HYD_SUFFIX_ROWS", "HYD_ROWS_UT", "HYD_ROWS_ROT", "HYD_ROWS_PIPE"):
             os.environ.pop(k, None)
         if v is None:
             return
         if ":" in v:
-            r_, u_, o_ = v.split(":")
-            os.environ.update(HYD_SUFFIX_ROWS=r_, HYD_ROWS_UT=u_, HYD_ROWS_ROT=o_)
+            r_, u_, o_, *p_ = v.split(":")  # optional 4th field (HYD_ROWS_PIPE): 0 = the first form (loads, then arithmetic), 1 / 2 = blind K requests, 3 = the product form
+            os.environ.update(HYD_SUFFIX_ROWS=r_, HYD_ROWS_UT=u_, HYD_ROWS_ROT=o_, HYD_ROWS_PIPE=p_[0] if p_ else "0")
         else:
             os.environ.update(HYD_SUFFIX_ROWS="0", HYD_SUFFIX_OCC=v)
 
@@ -237,13 +238,19 @@ def main():
         for cap in [int(x) for x in a.caps.split(",")]:
             held = []
             for rep_ in range(3):
-                for layout in ("2,B", "B,2"):
+                for layout in a.layouts.split(";"):
                     if layout == "2,B":
                         arena = torch.empty((2, B, cap, Hkv, D), dtype=dt, device=DEV)
                         kk, vv = arena[0], arena[1]
-                    else:
+                    elif layout == "B,2":
                         arena = torch.empty((B, 2, cap, Hkv, D), dtype=dt, device=DEV)
                         kk, vv = arena[:, 0], arena[:, 1]
+                    elif layout == "B,r,2":  # a token's K row, then its V row (16 KB contiguous per token at C2)
+                        arena = torch.empty((B, cap, 2, Hkv, D), dtype=dt, device=DEV)
+                        kk, vv = arena[:, :, 0], arena[:, :, 1]
+                    else:  # "B,r,H,2": a head's K row, then its V row (512 B contiguous per token and head)
+                        arena = torch.empty((B, cap, Hkv, 2, D), dtype=dt, device=DEV)
+                        kk, vv = arena[:, :, :, 0], arena[:, :, :, 1]
                     arena.normal_()
                     held.append(arena)  # keep it: the next allocation lands somewhere else
                     cells = []
