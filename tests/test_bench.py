@@ -169,6 +169,8 @@ def test_bench_single_gpu_line_is_complete():
     assert res["n_gpus"] == 1 and res["metric"] == "decode_attention_tokens_per_sec" and res["unit"] == "tokens/s"
     assert res["vs_baseline"] is None and res["dtype"] == "bf16" and res["data"] == "synthetic"
     assert len(res["trials"]["repeat_us_per_step"]) == 2
+    # timed steps are eager C calls; the same schedule as graph replays is timed beside them
+    assert res["step_forms"]["form"] == "eager" and res["trials"]["other_form"] == "graph" and res["trials"]["other_form_us_per_step"] > 0
     assert abs(res["trials"]["trial0_us_per_step"] / (res["ms_per_step"] * 1e3) - 1) < 1e-4  # (nested figures carry 5 digits)
     assert len(json.dumps(res)) < 8000 and res["detail_file"] == "gpurun_out/bench_detail.json"  # the driver keeps 8 KB
     detail = json.loads((REPO / res["detail_file"]).read_text())

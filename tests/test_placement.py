@@ -37,6 +37,21 @@ def test_cpu_allocation_is_plain_zeros():
     assert rep == {"candidates": 3, "probed": False, "why": "not a GPU allocation"}
 
 
+def test_kv_arena_puts_a_sequences_k_and_v_side_by_side():
+    """Logical [2, B, rows, H, D] (arena[0] / arena[1] = the reference's two caches, llama.py:186-198), memory [B, 2, rows, H, D]:
+    a sequence's V rows follow its K rows, consecutive sequences sit 2 x rows token rows apart, heads and dims stay contiguous."""
+    b, rows, h, d = 3, 16, 2, 64
+    arena = P.kv_arena((b, rows, h, d), torch.float16, "cpu")
+    assert arena.shape == (2, b, rows, h, d) and not arena.any()
+    k, v = arena[0], arena[1]
+    tok = h * d
+    assert k.stride() == (2 * rows * tok, tok, d, 1) == v.stride()
+    assert v.data_ptr() - k.data_ptr() == rows * tok * arena.element_size()           # V of sequence 0 right behind its K
+    assert k[1].data_ptr() - k[0].data_ptr() == 2 * rows * tok * arena.element_size()  # next sequence: 2 x rows further
+    k[1, 5, 1, 7] = 3.0  # the views alias one allocation
+    assert arena.permute(1, 0, 2, 3, 4).is_contiguous() and arena.permute(1, 0, 2, 3, 4)[1, 0, 5, 1, 7] == 3.0
+
+
 def test_set_candidates_returns_the_previous_setting():
     old = P.set_candidates(1)
     try:
