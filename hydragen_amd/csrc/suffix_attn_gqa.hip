@@ -342,6 +342,13 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         if (seg == 1) {
             asm volatile("" : "+v"(len_raw));
             len = max(0, min(len_raw, a.kv_len));
+            // From here on the windows end at the sequence's length: the rows of a step that reaches past it are zero-filled by
+            // the address check instead of being fetched (round 6: with the windows left at the cache's kv_len rows, every unit read
+            // up to 31 rows behind its length in its last step -- 15.5 on average, 1.17 x the algorithmic bytes at C5's mean suffix
+            // of 128.5, counted by FETCH_SIZE in profiles/r06_v4_c5_whole_job.json).  Only the blind first step above may still
+            // bring rows in [len, 32) into the tiles; `sanitize` and the score select deal with those as before.
+            krs_c[2] = __builtin_amdgcn_readfirstlane((unsigned)len * k_ts2);
+            vrs_c[2] = __builtin_amdgcn_readfirstlane((unsigned)len * v_ts2);
         }
         seg_len = seg == 0 ? a.p_len : len;
         if (!pre_folded) fold_pre();
