@@ -70,6 +70,7 @@ struct SuffixArgs {
     int32_t packed;  // shapes allow the lane-group path for short sequences (set by launch_suffix)
     int32_t n_pre;   // leading 16-bit partials the kernels fetch under the K/V stream (0..2, set by run_suffix)
     int32_t rows_wps_log2;  // token-row kernel (suffix_attn.hip): log2 of the waves of a workgroup that share one sequence (set by its launcher)
+    int32_t dbg_blind;  // 0 in product builds; HYD_ABLATION_BUILD: HYD_GQA_BLIND=1 restores the blind first key step of the grouped-query kernel (A/B)
     int32_t shared_kv;  // the keys are read by several workgroups (a small shared level on the grouped-query kernel): no non-temporal hint
     // grouped-query kernel only: a shared-prefix segment walked before the unit's own keys (tiny problems: the whole
     // operator in one launch).  Sequence b reads rows [0, p_len) of group b / p_per; token strides equal k_ts / v_ts.

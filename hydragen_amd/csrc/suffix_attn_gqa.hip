@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     const int b = (int)blockIdx.x - hkg * a.B;
     const int hk = hkg * HPW + (HPW == 1 ? 0 : wv), row0 = blockIdx.y * 16;
 
-    // the sequence's length is requested first and used last: q and the first partials are requested under its round trip
+    // the sequence's length is requested first (a scalar load): q and the first partials are requested under its round trip, the first
+    // key step goes out when it arrives
     int len_raw = a.kv_len;
     if (a.sl32) len_raw = a.sl32[b];
     else if (a.sl64) len_raw = (int)a.sl64[b];
@@ -330,29 +331,44 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         const int k_first = wave * 32;
         if (seg == 0) { krs_c = krs_p; vrs_c = vrs_p; seg_cap = a.p_len; }
         else { krs_c = krs; vrs_c = vrs; seg_cap = a.kv_len; }
-        // The first step is requested for whatever the window holds, BEFORE the sequence's length is known: the length, q, the first
-        // partials and the first tiles then share one round trip instead of two.  (A sequence shorter than k_first keys wastes it.)
-        const bool spec = seg_cap > k_first;
-        if (spec) issue(k_first);
+        // The first step goes out as soon as the sequence's length has arrived (a scalar load: its wait does not touch the vector
+        // queue), in front of the wait for q and the first partials, and its windows END at the length: a step that reaches past
+        // it is zero-filled by the address check instead of being fetched.  Until round 6 the first step was requested blind --
+        // before the length, for whatever the cache's kv_len rows held -- and the windows stayed that wide: every unit read up to 31
+        // rows behind its length in its last step (1.166 x the algorithmic bytes at C5's mean suffix of 128.5, FETCH_SIZE in
+        // profiles/r06_v4_c5_whole_job.json) and a full 32 rows in the first 31 decode steps of every generation (C5 at S = 20:
+        // 368 MB moved for 268 MB).  The round trip the blind step saved is 0.5 us per launch (profiles/r06_gqa_blind_step_ab.txt).
+        bool blind = false;
+#ifdef HYD_ABLATION_BUILD
+        blind = a.dbg_blind != 0;  // HYD_GQA_BLIND=1: the blind first step, windows still cut at the length afterwards (A/B)
+#endif
+        auto learn_len = [&]() __attribute__((always_inline)) {
+            if (seg == 1) {
+                len = max(0, min(len_raw, a.kv_len));
+                krs_c[2] = __builtin_amdgcn_readfirstlane((unsigned)len * k_ts2);
+                vrs_c[2] = __builtin_amdgcn_readfirstlane((unsigned)len * v_ts2);
+            }
+            seg_len = seg == 0 ? a.p_len : len;
+        };
+        int nst = 0;  // 32-key steps of this wave
+        if (blind) {
+            if (seg_cap > k_first) issue(k_first);
+        } else {
+            learn_len();
+            nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;
+            if (nst > 0) issue(k_first);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... all landed
-        // hipcc counts only its own loads (the length, q, the first partials): make it settle them HERE, where nothing is in flight -- a
+        // hipcc counts only its own loads (q, the first partials): make it settle them HERE, where nothing is in flight -- a
         // counted wait of its own further down would also wait for the next step's DMAs, which it does not know about
 #pragma unroll
         for (int c = 0; c < NCH; ++c) asm volatile("" ::"v"(qf[c]));
-        if (seg == 1) {
-            asm volatile("" : "+v"(len_raw));
-            len = max(0, min(len_raw, a.kv_len));
-            // From here on the windows end at the sequence's length: the rows of a step that reaches past it are zero-filled by
-            // the address check instead of being fetched (round 6: with the windows left at the cache's kv_len rows, every unit read
-            // up to 31 rows behind its length in its last step -- 15.5 on average, 1.17 x the algorithmic bytes at C5's mean suffix
-            // of 128.5, counted by FETCH_SIZE in profiles/r06_v4_c5_whole_job.json).  Only the blind first step above may still
-            // bring rows in [len, 32) into the tiles; `sanitize` and the score select deal with those as before.
-            krs_c[2] = __builtin_amdgcn_readfirstlane((unsigned)len * k_ts2);
-            vrs_c[2] = __builtin_amdgcn_readfirstlane((unsigned)len * v_ts2);
+        if (blind) {
+            if (seg == 1) asm volatile("" : "+v"(len_raw));
+            learn_len();
+            nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;
         }
-        seg_len = seg == 0 ? a.p_len : len;
         if (!pre_folded) fold_pre();
-        const int nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;  // 32-key steps of this wave
         for (int j = 0; j < nst; ++j) {
             const int key0 = k_first + j * stride;
             if (j > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step j's tiles have landed
@@ -480,6 +496,7 @@ static int launch_gqa_t(const SuffixArgs& a_in, hipStream_t s) {
     bool few_units = gqa_few_units(a, chunks);
 #ifdef HYD_ABLATION_BUILD
     if (const char* e = getenv("HYD_GQA_WPU")) few_units = atoi(e) == 4;
+    if (const char* e = getenv("HYD_GQA_BLIND")) a.dbg_blind = atoi(e);
 #endif
     // kv heads of a sequence per workgroup (one-wave units of the unique phase).  Measured with this kernel (profiles/r05_gqa_hpw.txt,
     // us at S = 32 / 128 / 256): 8 kv heads: 1 head per workgroup 61 / 197 / 364, 2: 60 / 185 / 355, 4: 64 / 184 / 352, 8: 71 / 187 / 341 -- a
