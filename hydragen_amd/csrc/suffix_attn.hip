@@ -139,7 +139,7 @@ __device__ __forceinline__ void suffix_packed_body(const SuffixArgs& a, int b, i
 // S = 64 175.8 -> 172.8 (-1.7 %), S = 128 340 -> 337; equal at S <= 4.  Requesting (half of) chunk 0's K BEFORE the length is
 // known (HS > 0, development builds) adds nothing on top (the launch is throughput-bound, not start-latency-bound) and costs
 // 1.5 us at S = 1..2 (rows past the length are fetched for nothing): not shipped.
-template <typename T, int D, int UT, int NPRE, int HS = 0>
+template <typename T, int D, int UT, int NPRE, int HS = 0, int TS = 1>
 __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     warm_kernargs_256();  // the fields in front of partials[1] span four scalar-cache lines: one miss time instead of five in a row
@@ -147,11 +147,16 @@ __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixAr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane % LPK, hg = lane / LPK;
+    static_assert(TS == 1 || HS == 0, "token split: no blind requests");
     // waves per sequence inside a workgroup: 4 (then blockIdx.y walks further head slices), 2 or 1
+    // TS > 1 (shapes with too few waves to fill the chip: a TP rank's shard, a small batch): TS waves share a (sequence, head slice)
+    // and deal its 8-token chunks round-robin -- wave t takes chunks t, t + TS, ... -- then hand their (m, l, acc) to wave 0 through LDS.
+    constexpr int TL = TS == 4 ? 2 : TS == 2 ? 1 : 0;
+    const int ts_id = wave & (TS - 1), wrest = wave >> TL;
     const int wl = a.rows_wps_log2;
-    const int b = (int)(blockIdx.x << (2 - wl)) + (wave >> wl);
-    const int h0 = (int)((blockIdx.y << wl) + (wave & ((1 << wl) - 1))) * HPI;  // first head of this wave
-    if (b >= a.B || h0 >= a.Hkv) return;
+    const int b = (int)(blockIdx.x << (2 - wl - TL)) + (wrest >> wl);
+    const int h0 = (int)((blockIdx.y << wl) + (wrest & ((1 << wl) - 1))) * HPI;  // first head of this wave
+    if (b >= a.B || h0 >= a.Hkv) return;  // (all TS waves of a group leave together: a barrier counts the waves that are left)
 
     // the length as a vector load: every lane the same address; an opaque zero keeps hipcc from making it a scalar load
     int zero = 0;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixAr
         }
         if constexpr (!is_last) {
             __builtin_amdgcn_sched_barrier(0);
-            issue_k(c + 1, 0);
+            issue_k(c + TS, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         float cmax = sv[0];
@@ -251,17 +256,35 @@ __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixAr
         }
         if constexpr (!is_last) {
             __builtin_amdgcn_sched_barrier(0);
-            issue_v(c + 1);
+            issue_v(c + TS);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if (nch > 0 || HS > 0) {  // (an empty sequence requests nothing: its cache may have no rows at all)
-        issue_k(0, HS);  // chunk 0 in the steady state's order: K, then V
-        issue_v(0);
+    if (nch > ts_id || HS > 0) {  // (a wave without a chunk requests nothing: an empty sequence's cache may have no rows at all)
+        issue_k(ts_id, HS);  // this wave's first chunk in the steady state's order: K, then V
+        issue_v(ts_id);
         __builtin_amdgcn_sched_barrier(0);
-        int c = 0;
-        for (; c + 1 < nch; ++c) chunk(c, std::integral_constant<bool, false>{});
-        if (nch > 0) chunk(c, std::integral_constant<bool, true>{});
+        int c = ts_id;
+        for (; c + TS < nch; c += TS) chunk(c, std::integral_constant<bool, false>{});
+        if (nch > ts_id) chunk(c, std::integral_constant<bool, true>{});  // this wave's last chunk: masked (it may be the sequence's last)
+    }
+    if constexpr (TS > 1) {
+        __shared__ float xch[4][10][64];  // [wave of the workgroup][m, l, acc[8]][lane]
+        if (ts_id > 0) {
+            xch[wave][0][lane] = m;
+            xch[wave][1][lane] = l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xch[wave][2 + j][lane] = acc[j];
+        }
+        __syncthreads();
+        if (ts_id > 0) return;
+#pragma unroll
+        for (int t = 1; t < TS; ++t) {
+            float a2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a2[j] = xch[wave + t][2 + j][lane];
+            merge_state(m, l, acc, xch[wave + t][0][lane], xch[wave + t][1][lane], a2);
+        }
     }
     finish_row<T, D, 2, NPRE>(a, ridx, sub, m, l, acc, npre, pp);
 }
@@ -385,7 +408,19 @@ static int launch_suffix_rows(const SuffixArgs& a0, hipStream_t s, int ut, int r
     const int wps = a.Hkv / HPI;  // waves per sequence
     a.rows_wps_log2 = wps >= 3 ? 2 : wps == 2 ? 1 : 0;
     const int wl = a.rows_wps_log2;
-    const dim3 grid((unsigned)((a.B + (4 >> wl) - 1) >> (2 - wl)), (unsigned)((wps + (1 << wl) - 1) >> wl), 1);
+    // Token split (shapes only).  When one wave covers all heads of a token (Hkv = the 64 / (D / 8) heads of a wave instruction: a
+    // 1 KB token row, a TP = 8 shard of C2), the 4 waves of a workgroup used to walk 4 different sequences, 8 KB of each at a time;
+    // sharing ONE sequence between 2 (4) of them -- 16 (32) KB of the same contiguous cache requested together -- streams 6-13 %
+    // faster from S = 16 on at every batch size (profiles/r06_suffix_rows_token_split_ab.txt: B = 1024, S = 64 28.5 -> 25.8 us,
+    // S = 128 51.4 -> 44.9; B = 8192, S = 64 183 -> 167); 2 is the better split up to 2048 sequences, 4 above (and the cheaper one at
+    // S = 8: + 0.5 us).  With two or more waves per sequence already (8 or more kv heads at D = 128) it changes nothing: not used.
+    int ts = 1;
+    if (wl == 0 && a.n_pre < 2 && a.kv_len >= 32) ts = a.B <= 2048 ? 2 : 4;
+#ifdef HYD_ABLATION_BUILD
+    if (const char* e = getenv("HYD_ROWS_TS")) { ts = atoi(e); if (wl + (ts == 4 ? 2 : ts == 2 ? 1 : 0) > 2 || a.n_pre >= 2) ts = 1; }
+#endif
+    const int tl = ts == 4 ? 2 : ts == 2 ? 1 : 0;
+    const dim3 grid((unsigned)((a.B + (4 >> (wl + tl)) - 1) >> (2 - wl - tl)), (unsigned)((wps + (1 << wl) - 1) >> wl), 1);
 #define HYD_ROWS_LAUNCH(KERNEL) \
     do { hipLaunchKernelGGL((KERNEL), grid, dim3(256), 0, s, a); return (int)hipGetLastError(); } while (0)
 #ifdef HYD_ABLATION_BUILD
@@ -403,6 +438,8 @@ static int launch_suffix_rows(const SuffixArgs& a0, hipStream_t s, int ut, int r
     (void)rot;
     (void)pipe;
     if (a.n_pre == 2) HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 2>));
+    if (ts == 4) HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 1, 0, 4>));
+    if (ts == 2) HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 1, 0, 2>));
     HYD_ROWS_LAUNCH((suffix_attn_rows_kernel<T, D, 8, 1>));
 #undef HYD_ROWS_LAUNCH
 }

@@ -2,7 +2,7 @@
 against the float64 oracle on the shapes that SELECT it -- one query row per kv head (nq = 1, Hq = Hkv), kv heads a multiple of
 the 64 / (D / 8) heads one wave instruction covers, at least 2048 (sequence, kv head) units, caches of at most 1024 rows -- which the
 small cases of test_primitives_gpu.py never reach.  Every geometry of its launcher (1, 2 or 4 waves per sequence inside a workgroup,
-a second workgroup row of heads), lengths around the 8-token chunk (0, 1, 7, 8, 9, 15, 16, 17, the cache's capacity), padding behind
+a second workgroup row of heads, 2 or 4 waves sharing one sequence's tokens when a wave covers all of a token's heads), lengths around the 8-token chunk (0, 1, 7, 8, 9, 15, 16, 17, the cache's capacity), padding behind
 a sequence's length poisoned with NaN / Inf (the kernel's requests are clamped, never predicated), 0 / 1 / 2 prefetched partials
 and an fp32 slice behind them, the K|V arena layout the model allocates ([batch, K|V, rows, heads, dim]: strided views), int64
 lengths.  Replaces flash_attention_seqlen + combine_lse (`/root/reference/hydragen/flash.py:163-281`, `attention.py:21-43`)."""
@@ -39,7 +39,9 @@ def _poison(x, sl, what):
 # B x Hkv >= 2048 units each; waves per sequence = Hkv / (64 / (D / 8))
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("D,B,H,cap", [
-    (128, 520, 4, 40),     # 1 wave per sequence: 4 sequences per workgroup, the last workgroup half empty (B % 4 = 0; 520 * 4 = 2080 units)
+    (128, 520, 4, 40),     # one wave covers a token's heads: 2 waves share a sequence (token split), 2 sequences per workgroup
+    (128, 521, 4, 24),     # ... a cache too short to split (< 32 rows): 4 sequences per workgroup, the last workgroup a quarter full
+    (128, 2100, 4, 40),    # ... more than 2048 sequences: 4 waves share a sequence
     (128, 258, 8, 33),     # 2 waves per sequence: 2 sequences per workgroup
     (128, 129, 16, 64),    # 4 waves per sequence: one sequence per workgroup
     (128, 66, 32, 128),    # C2's geometry: two workgroups (rows of heads) per sequence
@@ -83,6 +85,8 @@ def test_token_row_kernel_vs_oracle(dt, D, B, H, cap):
     (129, 16, 24, [("h", 1), ("h", 1), ("f", 1)]),   # a third, fp32 partial behind the prefetched two
     (258, 8, 17, [("s", 3)]),                        # split-KV slices only: nothing prefetched
     (520, 4, 9, [("h", 1), ("s", 4)]),               # a TP = 8 shard: one prefetched partial + 4 fp32 slices
+    (520, 4, 70, [("h", 1), ("s", 4)]),              # ... with caches long enough for the token split (2 waves per sequence)
+    (2100, 4, 33, [("s", 2)]),                       # ... 4 waves per sequence
 ])
 def test_token_row_kernel_folds_partials(dt, B, H, cap, parts):
     from hydragen_amd import _lib

@@ -163,12 +163,22 @@ def main():
             c5 = times(s, a.iters)
             print(f"| {S} | " + " | ".join(f"{x[0]:6.1f} / {x[1]:6.1f}" for x in (c0, c1, c2, c3, c4, c5)) + " |", flush=True)
 
+    _extra_keys = set()
+
     def set_variant(v):
         """occ leg: HYD_SUFFIX_OCC value; rows legs: 'ROWS:UT:ROT[:PIPE]' (token-row kernel on/off, tokens in flight, rotated start, pipelined form)."""
         for k in ("HYD_SUFFIX_OCC", "HYD_SUFFIX_ROWS", "HYD_ROWS_UT", "HYD_ROWS_ROT", "HYD_ROWS_PIPE"):
             os.environ.pop(k, None)
+        for k in [k for k in os.environ if k in _extra_keys]:
+            os.environ.pop(k)
         if v is None:
             return
+        if ";" in v:  # 'ROWS:UT:ROT:PIPE;NAME=value;...': further development switches of the ablation library (e.g. HYD_ROWS_TS=1)
+            v, *extra = v.split(";")
+            for kv in extra:
+                k_, val = kv.split("=")
+                os.environ[k_] = val
+                _extra_keys.add(k_)
         if ":" in v:
             r_, u_, o_, *p_ = v.split(":")  # optional 4th field (HYD_ROWS_PIPE): 0 = the first form (loads, then arithmetic), 1 / 2 = blind K requests, 3 = the product form
             os.environ.update(HYD_SUFFIX_ROWS=r_, HYD_ROWS_UT=u_, HYD_ROWS_ROT=o_, HYD_ROWS_PIPE=p_[0] if p_ else "0")
