@@ -44,7 +44,7 @@ class Partial(C.Structure):
 class SuffixParams(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p),
-        ("seq_lens_i32", C.c_void_p), ("seq_lens_i64", C.c_void_p),
+        ("seq_lens_i32", C.c_void_p), ("seq_lens_i64", C.c_void_p), ("seq_order", C.c_void_p),
         ("k_batch_stride", C.c_int64), ("k_tok_stride", C.c_int64), ("k_head_stride", C.c_int64),
         ("v_batch_stride", C.c_int64), ("v_tok_stride", C.c_int64), ("v_head_stride", C.c_int64),
         ("dtype", C.c_int32), ("B", C.c_int32), ("nq", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32),
@@ -147,7 +147,7 @@ EXPORTS = {
 }
 
 _lib = None
-ABI_VERSION = 400  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
+ABI_VERSION = 500  # HYD_VERSION of include/hydragen_hip.h these mirrors were written against
 
 
 def lib_path() -> Path:

@@ -327,11 +327,12 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
     # no cache while capturing (the scratch belongs to the graph's private pool) or with a head-dim override (padded temporaries)
     capturing = torch.cuda.is_current_stream_capturing()
     uncached = capturing or _flash.current_softmax_scale() != 0.0
+    order = _flash.current_seq_order()  # schedule hint (flash.seq_order); part of the cached block's identity, kept alive with it
     two_stream = _want_two_stream(q, k, shared_ks, shared_max_seq_lens, use_varlens, capturing)
     key = None
     stream = _stream()
     if not uncached:
-        key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), q.device.index, stream, threading.get_ident(), _f32_partials,
+        key = (_tensor_key(q), _tensor_key(k), _tensor_key(v), _tensor_key(seq_lens), _tensor_key(order), q.device.index, stream, threading.get_ident(), _f32_partials,
                tuple(_tensor_key(x) for x in shared_ks), tuple(_tensor_key(x) for x in shared_vs),
                tuple(_tensor_key(x) for x in shared_cu_seq_lens), tuple(shared_max_seq_lens), tuple(use_varlens))
         hit = _PARAM_CACHE.get(key)
@@ -341,7 +342,7 @@ def _decode_fused(q, k, v, shared_ks, shared_vs, shared_cu_seq_lens, shared_max_
             _launch_decode(lib, p, two_stream, stream)
             return out
     p = DecodeParams()
-    keep = [fill_suffix_params(p.suffix, q, k, v, seq_lens, out)]
+    keep = [fill_suffix_params(p.suffix, q, k, v, seq_lens, out), order]
     p.n_levels = len(shared_ks)
     p.f32_partials = 1 if _f32_partials else 0
     for i, (sk, sv, scu, smax, uv) in enumerate(

@@ -302,6 +302,7 @@ void fill_suffix_args(const hyd_suffix_params* p, SuffixArgs* ap) {
     a.lse = p->lse;
     a.sl32 = p->seq_lens_i32;
     a.sl64 = p->seq_lens_i64;
+    a.order = p->seq_order;
     a.k_bs = p->k_batch_stride;
     a.k_ts = p->k_tok_stride;
     a.k_hs = p->k_head_stride;

@@ -61,6 +61,7 @@ struct SuffixArgs {
     float* lse;
     const int32_t* sl32;
     const int64_t* sl64;
+    const int32_t* order;  // optional permutation of the sequences: the unit in dispatch slot i works on sequence order[i] (hyd_suffix_params.seq_order)
     int64_t k_bs, k_ts, k_hs, v_bs, v_ts, v_hs;
     int32_t B, nq, Hq, Hkv, g, kv_len;
     int32_t rows;  // nq * g

@@ -154,13 +154,15 @@ __global__ __launch_bounds__(256, 4) void suffix_attn_rows_kernel(const SuffixAr
     constexpr int TL = TS == 4 ? 2 : TS == 2 ? 1 : 0;
     const int ts_id = wave & (TS - 1), wrest = wave >> TL;
     const int wl = a.rows_wps_log2;
-    const int b = (int)(blockIdx.x << (2 - wl - TL)) + (wrest >> wl);
+    const int bslot = (int)(blockIdx.x << (2 - wl - TL)) + (wrest >> wl);
     const int h0 = (int)((blockIdx.y << wl) + (wrest & ((1 << wl) - 1))) * HPI;  // first head of this wave
-    if (b >= a.B || h0 >= a.Hkv) return;  // (all TS waves of a group leave together: a barrier counts the waves that are left)
+    if (bslot >= a.B || h0 >= a.Hkv) return;  // (all TS waves of a group leave together: a barrier counts the waves that are left)
 
     // the length as a vector load: every lane the same address; an opaque zero keeps hipcc from making it a scalar load
     int zero = 0;
     asm volatile("" : "+v"(zero));
+    // dispatch slot -> sequence: the caller's schedule (hyd_suffix_params.seq_order: longest first when lengths are ragged) or the index
+    const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[bslot + zero]) : bslot;
     int lenv = a.kv_len;
     if (a.sl32) lenv = a.sl32[b + zero];
     else if (a.sl64) lenv = (int)a.sl64[b + zero];
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256, OCC) void suffix_attn_kernel(const SuffixArgs 
     // is the fastest-varying index on purpose: measured A/B on MI355X (same run, S = 128..256), spreading
     // concurrently running workgroups over different sequences streams 5-10 % faster than walking the
     // head groups of one sequence (whose rows share HBM channels).
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;  // dispatch slot -> sequence (hyd_suffix_params.seq_order)
     const int hk = blockIdx.y * (4 / WPU) + wave / WPU;
     if (hk >= a.Hkv) return;  // uniform per unit (all WPU waves of a unit leave together)
     const int row0 = blockIdx.z * R;

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     const int l15 = lane & 15, g4 = lane >> 4;
     // workgroup -> (sequence, kv-head group): blockIdx.x runs over B * (Hkv / HPW) pairs, sequences fastest
     const int hkg = (int)blockIdx.x / a.B;
-    const int b = (int)blockIdx.x - hkg * a.B;
+    const int bslot = (int)blockIdx.x - hkg * a.B;
+    const int b = a.order ? a.order[bslot] : bslot;  // dispatch slot -> sequence (hyd_suffix_params.seq_order)
     const int hk = hkg * HPW + (HPW == 1 ? 0 : wv), row0 = blockIdx.y * 16;
 
     // the sequence's length is requested first (a scalar load): q and the first partials are requested under its round trip, the first

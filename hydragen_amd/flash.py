@@ -107,6 +107,46 @@ class true_head_dim_scale:
         _scale_var.reset(self.token)
 
 
+# ---- schedule hint for ragged unique lengths ---------------------------------------------------------------------------
+# The suffix kernels hand sequences to the chip in index order.  With ragged lengths the last workgroups of a launch are then
+# a random mix, the short ones leave, and the long ones finish on a half-empty chip: C2 heads, lengths 1..128 at random, 184 us
+# against 163 us for the same keys in equal rows (tests/probes/ragged_lengths_probe.py).  Handing the LONGEST sequences out
+# first brings that to 169 us.  Only the caller can know the order cheaply -- during decode every length grows by one per step, so
+# one argsort at the start of a generation serves all of its steps (hydragen_amd/llama.py does that) -- and the reference's
+# operator signatures (attention.py:177-392, flash.py:163-281) have no argument for it, so it travels like the softmax scale
+# above: a context variable that the marshalling helpers forward to hyd_suffix_params.seq_order.  None = index order.
+_order_var: contextvars.ContextVar = contextvars.ContextVar("hydragen_amd_seq_order", default=None)
+
+
+def current_seq_order() -> Tensor | None:
+    return _order_var.get()
+
+
+def longest_first(seq_lens: Tensor) -> Tensor:
+    """The schedule for `seq_lens` [B]: int32 permutation, longest sequence first (stable)."""
+    return torch.argsort(seq_lens, descending=True, stable=True).to(torch.int32).contiguous()
+
+
+class seq_order:
+    """with seq_order(perm): suffix passes marshalled inside hand sequence perm[i] to dispatch slot i.  `perm`: int32 [B] on the
+    device, a permutation of 0..B-1 (checked here once, on entry: the kernels trust it), or None."""
+
+    def __init__(self, perm: Tensor | None, check: bool = True):
+        if perm is not None:
+            if perm.dtype != torch.int32 or perm.ndim != 1 or not perm.is_contiguous():
+                raise ValueError(f"seq_order: contiguous int32 [B] expected, got {perm.dtype} {tuple(perm.shape)}")
+            if check and not torch.equal(torch.sort(perm).values, torch.arange(perm.numel(), dtype=torch.int32, device=perm.device)):
+                raise ValueError("seq_order: not a permutation of 0..B-1")
+        self.perm = perm
+
+    def __enter__(self):
+        self.token = _order_var.set(self.perm)
+        return self
+
+    def __exit__(self, *exc):
+        _order_var.reset(self.token)
+
+
 def prefix_attention(
     q: Tensor, k: Tensor, v: Tensor, *, sb: int, kv_len: int, group_stride: tuple[int, int],
     tok_stride: tuple[int, int], head_stride: tuple[int, int], B: int, nq: int, causal: bool,
@@ -223,6 +263,11 @@ def fill_suffix_params(p: SuffixParams, q: Tensor, k: Tensor, v: Tensor, seq_len
     p.B, p.nq, p.Hq, p.Hkv, p.D = b, nq, hq, k.shape[2], d
     p.kv_len = k.shape[1]
     p.softmax_scale = _scale_var.get()
+    order = _order_var.get()
+    if order is not None:
+        if order.numel() != b or order.device != q.device:
+            raise ValueError(f"seq_order has {order.numel()} entries on {order.device} for a batch of {b} on {q.device}")
+        p.seq_order = order.data_ptr()
     keep = None
     if seq_len is not None:
         assert seq_len.shape == (b,), f"{seq_len.shape}"

@@ -44,7 +44,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
 #define HYD_API __attribute__((visibility("default")))
 
-#define HYD_VERSION 400 /* 0.4.0: hyd_add_rmsnorm, hyd_swiglu, hyd_sample_tokens (model-shell glue); 0.3.0: two-stream phases + hyd_decode_params.shared_max_workgroups, hyd_decode_two_stream_ok; 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
+#define HYD_VERSION 500 /* 0.5.0: hyd_suffix_params.seq_order (schedule hint for ragged lengths); 0.4.0: hyd_add_rmsnorm, hyd_swiglu, hyd_sample_tokens (model-shell glue); 0.3.0: two-stream phases + hyd_decode_params.shared_max_workgroups, hyd_decode_two_stream_ok; 0.2.2: hyd_allreduce_params.timeout_log2_polls; 0.2.1: softmax_scale; 0.2.0: hyd_decode_params.phase, hyd_rope_params.max_pos, hyd_allreduce_* */
 #define HYD_MAX_LEVELS 8
 
 enum {
@@ -118,6 +118,14 @@ typedef struct hyd_suffix_params {
     const int32_t* seq_lens_i32; /* [B] or NULL                                                */
     const int64_t* seq_lens_i64; /* [B] or NULL (the reference's callers hold int64:           */
                                  /*   llama.py:569); both NULL = every sequence uses kv_len    */
+    const int32_t* seq_order;    /* [B] or NULL: a PERMUTATION of 0..B-1, the order in which   */
+                                 /*   the sequences are handed to the chip (longest first keeps */
+                                 /*   the last workgroups short when lengths are ragged: C2     */
+                                 /*   heads, lengths 1..128 at random: 184 -> 169 us).  Only   */
+                                 /*   the schedule depends on it, never a result; the caller    */
+                                 /*   vouches that it is a permutation.  During decode every    */
+                                 /*   length grows by one per step, so one argsort at the start */
+                                 /*   of a generation serves all of its steps.                  */
     int64_t k_batch_stride, k_tok_stride, k_head_stride;
     int64_t v_batch_stride, v_tok_stride, v_head_stride;
     int32_t dtype;

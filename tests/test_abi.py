@@ -20,7 +20,7 @@ def test_exports_match_header():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
-    assert lib.hyd_version() == 400 == _lib.ABI_VERSION
+    assert lib.hyd_version() == 500 == _lib.ABI_VERSION
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
