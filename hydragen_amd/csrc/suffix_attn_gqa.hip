@@ -54,14 +54,19 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     constexpr int RPI = 1024 / RB;   // rows per DMA instruction
     constexpr int NVD = 32 / RPI;    // DMA instructions per 32-key tile
     constexpr int TILE = 32 * RB;    // bytes of one 32-key tile (= 16 rows * D floats: reused by the merge)
+    // NSET tile sets per wave = key steps in flight.  A 32-key step is 2 x 4 KB at D = 64 -- half of what a D = 128 wave keeps in
+    // flight, and the kernel is bound by exactly that (profiles/r06_head_dim_rates.txt: 4.9-5.7 TB/s at D = 64 against 5.6-6.1 at
+    // 128) -- so D = 64 keeps TWO steps in flight: step j + 2 is requested into the set step j has just been read out of.
+    constexpr int NSET = D == 64 ? 2 : 1;
+    constexpr unsigned SETB = 2 * TILE;  // bytes of one set (K tile, V tile)
     // dynamic LDS: per wave one K and one V landing tile, then the merge's [NWV][4][16] floats
     extern __shared__ __attribute__((aligned(1024))) char gqa_smem[];
-    char(*tiles)[2][TILE] = reinterpret_cast<char(*)[2][TILE]>(gqa_smem);  // [wave][0 = K, 1 = V]
-    float(*mlx)[4][16] = reinterpret_cast<float(*)[4][16]>(gqa_smem + NWV * 2 * TILE);
+    char(*tiles)[NSET][2][TILE] = reinterpret_cast<char(*)[NSET][2][TILE]>(gqa_smem);  // [wave][set][0 = K, 1 = V]
+    float(*mlx)[4][16] = reinterpret_cast<float(*)[4][16]>(gqa_smem + NWV * NSET * 2 * TILE);
     const int wv = NWV == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave of the workgroup
     const int wave = WPU == 1 ? 0 : wv;                                                      // wave of the unit
-    char* ktile = tiles[wv][0];
-    char* vtile = tiles[wv][1];
+    char* ktile = tiles[wv][0][0];
+    char* vtile = tiles[wv][0][1];
 
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, g4 = lane >> 4;
@@ -200,23 +205,24 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     // instruction, every quarter wave 16 different cache lines -- and ran 10 % below this one on 8-kv-head shapes.)
     u32x4 kf[2][NCH];
     u32x4 vf[NDB];
-    auto issue = [&](int key0) __attribute__((always_inline)) {
+    // (so: byte offset of the tile set, 0 when there is one)
+    auto issue = [&](int key0, unsigned so) __attribute__((always_inline)) {
         const unsigned ksoff = (unsigned)key0 * k_ts2, vsoff = (unsigned)key0 * v_ts2;
 #pragma unroll
-        for (int i = 0; i < NVD; ++i) dma16_g<NT>(krs_c, kvoff[i], ksoff, kt0 + i * 1024);
+        for (int i = 0; i < NVD; ++i) dma16_g<NT>(krs_c, kvoff[i], ksoff, kt0 + so + i * 1024);
 #pragma unroll
-        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs_c, vvoff[i], vsoff, vt0 + i * 1024);
+        for (int i = 0; i < NVD; ++i) dma16_g<NT>(vrs_c, vvoff[i], vsoff, vt0 + so + i * 1024);
     };
-    auto collect = [&]() __attribute__((always_inline)) {
+    auto collect = [&](unsigned so) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
-                kf[h][c] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(kaddr[h] + (unsigned)(((4 * c + g4) ^ kswz) << 4)));
+                kf[h][c] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)(kaddr[h] + so + (unsigned)(((4 * c + g4) ^ kswz) << 4)));
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-            const u32x2 t0 = lds_tr16_g(vaddr[db]);
-            const u32x2 t1 = lds_tr16_g(vaddr[db] + 16 * RB);
+            const u32x2 t0 = lds_tr16_g(vaddr[db] + so);
+            const u32x2 t1 = lds_tr16_g(vaddr[db] + so + 16 * RB);
             vf[db] = u32x4{t0[0], t0[1], t1[0], t1[1]};
         }
         // every read has returned before the tiles are handed to the next DMA (asm: hipcc does not order it against them otherwise)
@@ -353,11 +359,11 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         };
         int nst = 0;  // 32-key steps of this wave
         if (blind) {
-            if (seg_cap > k_first) issue(k_first);
+            if (seg_cap > k_first) issue(k_first, 0u);
         } else {
             learn_len();
             nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;
-            if (nst > 0) issue(k_first);
+            if (nst > 0) issue(k_first, 0u);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... all landed
         // hipcc counts only its own loads (q, the first partials): make it settle them HERE, where nothing is in flight -- a
@@ -370,12 +376,19 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
             nst = seg_len > k_first ? (seg_len - k_first + stride - 1) / stride : 0;
         }
         if (!pre_folded) fold_pre();
+        // the second set's first step goes out BEHIND the drain: hipcc's own wait for q and the partials (it lands at the settle point
+        // above) is a full one and must not find a key step it does not know about in the queue
+        if (NSET == 2 && nst > 1) issue(k_first + stride, SETB);
         for (int j = 0; j < nst; ++j) {
             const int key0 = k_first + j * stride;
-            if (j > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step j's tiles have landed
-            collect();
+            const unsigned so = NSET == 2 ? (unsigned)(j & 1) * SETB : 0u;
+            if (j > 0) {  // step j's tiles have landed (requests return in order: with two sets, step j + 1's 2 NVD may stay out)
+                if (NSET == 2 && j + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NVD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            collect(so);
             if (key0 + 32 > seg_len) sanitize(key0);
-            if (j + 1 < nst) issue(key0 + stride);  // in flight while step j is computed
+            if (j + NSET < nst) issue(key0 + NSET * stride, so);  // in flight while steps j (and j + 1) are computed
             compute(key0);
         }
     }
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
         if (wave != 0) return;
 #pragma unroll
         for (int w = 1; w < WPU; ++w) {
-            const float* oth = reinterpret_cast<const float*>(tiles[w][1]);
+            const float* oth = reinterpret_cast<const float*>(tiles[w][0][1]);
             const float m2 = mlx[w][0][l15], l2 = mlx[w][1][l15];
             const float mf = fmaxf(m_run, m2);
             const float ms = (mf == -INFINITY) ? 0.f : mf;
@@ -471,7 +484,7 @@ static int launch_gqa_k(const SuffixArgs& a, dim3 grid, size_t pad, hipStream_t 
     constexpr int NWV = WPU * HPW;
     // the K/V landing tiles, plus the (m, l) exchange area that only the cross-wave merge of WPU > 1 touches: one-wave units ask
     // for the tiles alone, which is at most 64 KB for every shape picked from shapes (HPW = 4 at D = 128, HPW = 2 at D = 256)
-    constexpr size_t lds = (size_t)NWV * 2 * 32 * D * 2 + (WPU > 1 ? (size_t)NWV * 4 * 16 * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)NWV * (D == 64 ? 2 : 1) * 2 * 32 * D * 2 + (WPU > 1 ? (size_t)NWV * 4 * 16 * sizeof(float) : 0);
     auto kern = suffix_attn_gqa_kernel<T, D, WPU, NT, HPW>;
     if (lds + pad > 64 * 1024) {
         // more than the default dynamic-LDS limit (four-wave units; development pads): raise it, once per DEVICE and instantiation --
