@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * WPU * HPW) __attribute__((amdgpu_waves_per_eu(
     // collect: the landed tiles -> registers (K: 2 NCH ds_read_b128 in the A-operand layout; V^T: 2 NDB transposing reads), after
     //          which both tiles are free for the next step's DMA
     // compute: S^T = K Q^T, online softmax, O^T += V^T P^T, all from registers
-    // The loop keeps ONE step in flight per wave while the previous one is computed (collect(j); issue(j + 1); compute(j)):
+    // The loop keeps ONE step in flight per wave while the previous one is computed (collect(j); issue(j + 1); compute(j); head dim 64: TWO, NSET):
     // 16 KiB per wave, 8 waves per CU.  (Round 4's form loaded K straight into MFMA operand layout -- 16 rows x 64 B per
     // instruction, every quarter wave 16 different cache lines -- and ran 10 % below this one on 8-kv-head shapes.)
     u32x4 kf[2][NCH];
