@@ -9,10 +9,12 @@ from hydragen_amd import placement
 from hydragen_amd.flash import flash_attention_seqlen, longest_first, seq_order
 
 DEV, dt = "cuda:0", torch.bfloat16
-B, H, D, cap = 1024, 32, 128, 128
+# python ragged_lengths_probe.py [B Hq Hkv cap]   (default: C2 heads, 128-row caches; "2048 64 8 256" = whole-job C5)
+B, HQ, H, cap = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (1024, 32, 32, 128)
+D = 128
 g = torch.Generator(device=DEV).manual_seed(0)
-q = torch.randn(B, 1, H, D, device=DEV, dtype=dt, generator=g)
-(arena,), _ = placement.place_kv_arenas(1, (B, cap, H, D), dt, DEV, H, zero=False)
+q = torch.randn(B, 1, HQ, D, device=DEV, dtype=dt, generator=g)
+(arena,), _ = placement.place_kv_arenas(1, (B, cap, H, D), dt, DEV, HQ, zero=False)
 arena.normal_()
 
 
@@ -30,14 +32,15 @@ def timed(lens, iters=40):
     return torch.tensor([evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(iters)]).median().item()
 
 
-rnd = torch.randint(1, 129, (B,), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+rnd = torch.randint(1, cap + 1, (B,), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+lo, hi = cap // 8, cap - cap // 8
 cases = {
-    "uniform 64": torch.full((B,), 64, dtype=torch.int32),
-    "random 1..128": rnd,
+    f"uniform {cap // 2}": torch.full((B,), cap // 2, dtype=torch.int32),
+    f"random 1..{cap}": rnd,
     "random, sorted ascending": rnd.sort().values,
     "random, sorted descending": rnd.sort(descending=True).values,
-    "half 16 / half 112 (interleaved)": torch.tensor([16, 112] * (B // 2), dtype=torch.int32),
-    "half 16 then half 112": torch.tensor([16] * (B // 2) + [112] * (B // 2), dtype=torch.int32),
+    f"half {lo} / half {hi} (interleaved)": torch.tensor([lo, hi] * (B // 2), dtype=torch.int32),
+    f"half {lo} then half {hi}": torch.tensor([lo] * (B // 2) + [hi] * (B // 2), dtype=torch.int32),
 }
 print("| lengths | keys in total | us (b2b median) | TB/s of K/V + q / out | us with flash.seq_order(longest_first(lens)) | us with the identity order |")
 print("|---|---|---|---|---|---|")
@@ -50,5 +53,5 @@ for name, lens in cases.items():
         us_o = timed(ld)
     with seq_order(ident):
         us_i = timed(ld)
-    byts = tot * H * D * 2 * 2 + 2 * B * H * D * 2
+    byts = tot * H * D * 2 * 2 + 2 * B * HQ * D * 2
     print(f"| {name} | {tot} | {us:7.1f} | {byts / us / 1e6:5.2f} | {us_o:7.1f} | {us_i:7.1f} |", flush=True)
