@@ -41,6 +41,7 @@ def _poison(x, sl, what):
 @pytest.mark.parametrize("D,B,H,cap", [
     (128, 520, 4, 40),     # one wave covers a token's heads: 2 waves share a sequence (token split), 2 sequences per workgroup
     (128, 521, 4, 24),     # ... a cache too short to split (< 32 rows): 4 sequences per workgroup, the last workgroup a quarter full
+    (128, 521, 4, 48),     # ... split, odd batch: the last workgroup's second pair of waves leaves before the barrier of the first
     (128, 2100, 4, 40),    # ... more than 2048 sequences: 4 waves share a sequence
     (128, 258, 8, 33),     # 2 waves per sequence: 2 sequences per workgroup
     (128, 129, 16, 64),    # 4 waves per sequence: one sequence per workgroup
