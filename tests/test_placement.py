@@ -112,3 +112,24 @@ def test_the_real_probe_times_a_suffix_pass_and_leaves_the_arena_alone():
         assert rep == {"candidates": 1, "probed": False, "why": "probing off"} and not arena.any()
     finally:
         P.set_candidates(old)
+
+
+def test_longest_first_schedule_and_its_entry_check():
+    """`flash.longest_first` / `flash.seq_order` (the schedule hint behind hyd_suffix_params.seq_order): host logic, no GPU needed."""
+    from hydragen_amd.flash import current_seq_order, longest_first, seq_order
+
+    lens = torch.tensor([5, 9, 5, 0, 12, 9], dtype=torch.int32)
+    order = longest_first(lens)
+    assert order.dtype == torch.int32 and order.tolist() == [4, 1, 5, 0, 2, 3]  # stable: equal lengths keep their index order
+    assert current_seq_order() is None
+    with seq_order(order):
+        assert current_seq_order() is order
+        with seq_order(None):
+            assert current_seq_order() is None
+        assert current_seq_order() is order
+    assert current_seq_order() is None
+    with pytest.raises(ValueError, match="not a permutation"):
+        seq_order(torch.tensor([0, 1, 1], dtype=torch.int32))
+    with pytest.raises(ValueError, match="int32"):
+        seq_order(torch.tensor([0, 1, 2]))
+    seq_order(torch.tensor([0, 1, 1], dtype=torch.int32), check=False)  # the caller may vouch for it (the model shell does)
