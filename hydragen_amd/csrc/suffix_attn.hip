@@ -448,7 +448,7 @@ static int launch_suffix_rows(const SuffixArgs& a0, hipStream_t s, int ut, int r
 
 // NPRE: 16-bit partials fetched under the K/V stream (suffix_common.h); 2 is instantiated for the decode shape only
 // (R = 1, one wave per unit) and launched when the call has two such partials (a two-level hierarchy).
-template <typename T, int D, int R, int WPU, int NPRE = 1, int U_ = 4, int OCC = (R == 1 ? 6 : 1)>
+template <typename T, int D, int R, int WPU, int NPRE = 1, int U_ = 4, int OCC = (R == 1 ? 6 : 1), int PIPE = 0>
 __global__ __launch_bounds__(256, OCC) void suffix_attn_kernel(const SuffixArgs a) {
     using TR = Traits<T>;
     constexpr int LPK = D / 8;    // lanes per key row
@@ -594,7 +594,91 @@ __global__ __launch_bounds__(256, OCC) void suffix_attn_kernel(const SuffixArgs 
         }
     };
     int it = 0;
-    for (; it + U <= niter; it += U) chunk(std::integral_constant<int, U>{}, it);
+    if constexpr (PIPE != 0) {
+        // Long caches (more than 1024 rows: the token-row kernel does not take them): the full chunks with rotated requests, as in the
+        // token-row kernel -- K of chunk c + 1 goes out as soon as the scores of chunk c have left the K registers, V of chunk c + 1
+        // behind P.V of chunk c -- the same registers, never an empty queue.  2176-row caches, C2 heads, one process, alternating
+        // (profiles/r06_unit_kernel_rotated_ab.txt): S = 64 188.7 -> 183.6 us, S = 512 1319 -> 1298, S = 2176 5401 -> 5337;
+        // on 128- and 1024-row caches it loses 1-4 %, so only caches beyond 1024 rows take it.
+        const int nfull = niter / U;
+        if (nfull > 0) {
+            u32x4 kreg[U], vreg[U];
+            auto key_of = [&](int c, int u) __attribute__((always_inline)) { return ((c * U + u) * WPU + wv) * KPI + ks; };
+            auto issue_k = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    kreg[u] = __builtin_nontemporal_load((gu32x4_p)(kbu + ((unsigned)min(key_of(c, u), len - 1) * krs + sub * 16)));
+            };
+            auto issue_v = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    vreg[u] = __builtin_nontemporal_load((gu32x4_p)(vbu + ((unsigned)min(key_of(c, u), len - 1) * vrs + sub * 16)));
+            };
+            auto body = [&](int c, auto MORE) __attribute__((always_inline)) {
+                constexpr bool more = decltype(MORE)::value;
+                float s[R][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool valid = key_of(c, u) < len;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d = TR::dot2(qp[r][i], kreg[u][i], d);
+                        d = group_sum<LPK>(d);
+                        s[r][u] = valid ? d * sc : -INFINITY;
+                    }
+                }
+                if constexpr (more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_k(c + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float cmax = s[r][0];
+#pragma unroll
+                    for (int u = 1; u < U; ++u) cmax = fmaxf(cmax, s[r][u]);
+                    const float mnew = fmaxf(m[r], cmax);
+                    const float ms = (mnew == -INFINITY) ? 0.f : mnew;
+                    const float alpha = fast_exp2(m[r] - ms);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        s[r][u] = fast_exp2(s[r][u] - ms);
+                        ps += s[r][u];
+                    }
+                    l[r] = l[r] * alpha + ps;
+                    m[r] = mnew;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][j] *= alpha;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float vf[8];
+                    widen8<T>(vreg[u], vf);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(s[r][u], vf[j], acc[r][j]);
+                }
+                if constexpr (more) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_v(c + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            issue_k(0);
+            issue_v(0);
+            __builtin_amdgcn_sched_barrier(0);
+            int c = 0;
+            for (; c + 1 < nfull; ++c) body(c, std::integral_constant<bool, true>{});
+            body(c, std::integral_constant<bool, false>{});
+            it = nfull * U;
+        }
+    } else {
+        for (; it + U <= niter; it += U) chunk(std::integral_constant<int, U>{}, it);
+    }
     for (; it < niter; ++it) chunk(std::integral_constant<int, 1>{}, it);
 
     // ---- merge the KPI lane groups of the wave (butterfly: every lane ends with the total) -----
@@ -675,6 +759,12 @@ static int launch_suffix_r(const SuffixArgs& a, hipStream_t s) {
         if constexpr (R == 1) {
             if (a.n_pre == 2) {
                 hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 2>), grid, dim3(256), 0, s, a);
+                return (int)hipGetLastError();
+            }
+        }
+        if constexpr (R == 1) {
+            if (a.kv_len > 1024) {  // long caches: rotated requests (see PIPE in the kernel)
+                hipLaunchKernelGGL((suffix_attn_kernel<T, D, R, 1, 1, 4, 6, 1>), grid, dim3(256), 0, s, a);
                 return (int)hipGetLastError();
             }
         }

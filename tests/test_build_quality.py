@@ -19,7 +19,7 @@ LIMITS = {
     # 2 waves / SIMD: K and V fragments of a step live in registers (one K and one V landing tile of LDS per wave)
     "suffix_attn_gqa.hip": [(r"suffix_attn_gqa_kernel", 256)],
     # <T, D, R = 1, WPU = 1, NPRE, U, OCC>, one-unit-per-wave MHA decode: 6 waves / SIMD; the token-row kernel: 4 waves / SIMD (8 tokens x 2 tensors, requests rotated)
-    "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\d\w+?ELi(64|128|256)ELi1ELi1ELi\dELi\dELi\dEEv", 80),
+    "suffix_attn.hip": [(r"suffix_attn_kernel", 512), (r"suffix_attn_kernelINS_\d\w+?ELi(64|128|256)ELi1ELi1ELi\dELi\dELi\d(ELi\d)?EEv", 80),
                         (r"suffix_attn_rows_kernel", 128)],
     "combine.hip": [(r"combine", 128)],
     "rope_append.hip": [(r"rope_append", 128)],
